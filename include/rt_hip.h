@@ -1,0 +1,277 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X path-tracing back end (librt_hip.so).
+ *
+ * The reference (nonl4331/raytracing-rust) has no FFI; the narrowest seam that carries
+ * whole-image work is the trait method
+ *     Sampler::sample_image(RenderOptions, &Camera, &AccelerationStructure, callback)
+ *     crates/implementations/src/samplers/mod.rs:7-20, implemented by RandomSampler
+ *     (samplers/random_sampler.rs:10-99) and called only from Scene::render (src/scene.rs:35-42).
+ * This header is what a Rust `extern "C"` block would bind to put a GPU `impl Sampler`
+ * behind that seam (binding text: INTEGRATION.md).  Plain pointers and sizes only.
+ *
+ * Every POD below mirrors a reference type; the citation next to it is the type it
+ * replaces.  All floats are f32 (rt_core/src/lib.rs:23-32), vectors are 3 packed floats
+ * (Vec3 is #[repr(C)] {x,y,z}: rt_core/src/vec.rs:108-114).
+ *
+ * The random stream and the elementary functions are fixed by include/rt_detmath.h, so
+ * that rt_render(seed) is reproducible (the reference itself is unseeded).
+ *
+ * Error convention: functions return RT_OK (0) or a negative rt_status; the message is
+ * available from rt_last_error() (thread local).  Nothing aborts, nothing throws.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef enum rt_status {
+	RT_OK = 0,
+	RT_ERR_INVALID_ARGUMENT = -1,
+	RT_ERR_NO_DEVICE = -2,
+	RT_ERR_HIP = -3,
+	RT_ERR_OUT_OF_MEMORY = -4,
+	RT_ERR_UNSUPPORTED = -5
+} rt_status;
+
+/* ---- textures: enum AllTextures, crates/implementations/src/textures/mod.rs:18-25 ---- */
+typedef enum rt_texture_type {
+	RT_TEX_CHECKERED = 0, /* CheckeredTexture  textures/mod.rs:27-73  */
+	RT_TEX_SOLID = 1,     /* SolidColour       textures/mod.rs:182-200 */
+	RT_TEX_IMAGE = 2,     /* ImageTexture      textures/mod.rs:202-266 (decoded pixels only) */
+	RT_TEX_LERP = 3,      /* Lerp              textures/mod.rs:268-291 */
+	RT_TEX_PERLIN = 4     /* Perlin            textures/mod.rs:75-180 */
+} rt_texture_type;
+
+typedef struct rt_texture_desc {
+	int32_t type;
+	float colour_one[3]; /* solid: colour; lerp/checkered: colour_one (".ssml" `primary`) */
+	float colour_two[3]; /* lerp/checkered: colour_two (`secondary`) */
+	/* image: row-major RGB f32 as `to_rgb32f()` yields, true width/height in pixels
+	 * (the reference stores width-1/height-1 in `dim`, textures/mod.rs:232) */
+	const float *image_rgb;
+	uint32_t image_width;
+	uint32_t image_height;
+	/* perlin: ran_vecs[256][3], then perm_x[256], perm_y[256], perm_z[256] */
+	const float *perlin_ran_vecs;
+	const uint32_t *perlin_perm;
+} rt_texture_desc;
+
+/* ---- materials: enum AllMaterials, crates/implementations/src/materials/mod.rs:18-25 ---- */
+typedef enum rt_material_type {
+	RT_MAT_EMIT = 0,             /* materials/emissive.rs:5-39         param = strength */
+	RT_MAT_LAMBERTIAN = 1,       /* materials/lambertian.rs:5-51       param = albedo   */
+	RT_MAT_TROWBRIDGE_REITZ = 2, /* materials/trowbridge_reitz.rs:5-92 param = the stored
+	                                `alpha` field, i.e. roughness*roughness (:17-24) */
+	RT_MAT_REFLECT = 3,          /* materials/reflect.rs:7-43          param = fuzz     */
+	RT_MAT_REFRACT = 4           /* materials/refract.rs:8-56          param = eta      */
+} rt_material_type;
+
+typedef struct rt_material_desc {
+	int32_t type;
+	uint32_t texture; /* index into rt_scene_desc.textures */
+	float param;
+	float ior[3];   /* TrowbridgeReitz only */
+	float metallic; /* TrowbridgeReitz only */
+} rt_material_desc;
+
+/* ---- primitives: enum AllPrimitives, crates/implementations/src/primitives/mod.rs:14-19 ---- */
+typedef enum rt_primitive_type {
+	RT_PRIM_SPHERE = 0,       /* primitives/sphere.rs:9-27   */
+	RT_PRIM_TRIANGLE = 1,     /* primitives/triangle.rs:11-29 */
+	RT_PRIM_MESH_TRIANGLE = 2 /* primitives/triangle.rs:31-56 */
+} rt_primitive_type;
+
+typedef struct rt_primitive_desc {
+	int32_t type;
+	uint32_t material; /* index into rt_scene_desc.materials */
+	union {
+		struct {
+			float centre[3];
+			float radius;
+		} sphere;
+		struct {
+			uint32_t mesh; /* index into rt_scene_desc.meshes */
+			uint32_t point_indices[3];
+			uint32_t normal_indices[3];
+		} mesh_triangle;
+		struct {
+			uint64_t data; /* index into rt_scene_desc.triangles */
+		} triangle;
+	} u;
+} rt_primitive_desc;
+
+/* Triangle { points: [Vec3;3], normals: [Vec3;3] }  primitives/triangle.rs:11-15 */
+typedef struct rt_triangle_data {
+	float points[9];
+	float normals[9];
+} rt_triangle_data;
+
+/* MeshData { vertices: Vec<Vec3>, normals: Vec<Vec3> }  primitives/triangle.rs:58-67 */
+typedef struct rt_mesh_desc {
+	const float *vertices;
+	uint64_t n_vertices;
+	const float *normals;
+	uint64_t n_normals;
+} rt_mesh_desc;
+
+/* Sky::new(texture, mat, sampler_res)  crates/implementations/src/sky.rs:13-39 */
+typedef struct rt_sky_desc {
+	uint32_t texture;
+	uint32_t material; /* the loader makes Emit(texture, 1.0): loader/src/misc.rs:27 */
+	uint32_t sampler_res_x;
+	uint32_t sampler_res_y; /* (0,0) disables importance sampling: sky.rs:61-63 */
+} rt_sky_desc;
+
+/* enum SplitType  acceleration/split.rs:34-45 */
+typedef enum rt_split_type { RT_SPLIT_SAH = 0, RT_SPLIT_MIDDLE = 1, RT_SPLIT_EQUAL_COUNTS = 2 } rt_split_type;
+
+/* Everything Bvh::new(primitives, sky, split_type) consumes (acceleration/mod.rs:58-93),
+ * flattened out of the Region arena (crates/region) the reference keeps it in. */
+typedef struct rt_scene_desc {
+	uint32_t abi_version; /* RT_ABI_VERSION */
+	uint32_t n_textures;
+	const rt_texture_desc *textures;
+	uint32_t n_materials;
+	uint32_t n_meshes;
+	const rt_material_desc *materials;
+	const rt_mesh_desc *meshes;
+	uint64_t n_primitives;
+	const rt_primitive_desc *primitives;
+	uint64_t n_triangles;
+	const rt_triangle_data *triangles;
+	rt_sky_desc sky;
+	int32_t split_type;
+} rt_scene_desc;
+
+/* SimpleCamera's four ray-generating fields  crates/implementations/src/camera.rs:6-17 */
+typedef struct rt_camera {
+	float origin[3];
+	float lower_left[3];
+	float horizontal[3];
+	float vertical[3];
+} rt_camera;
+
+/* enum RenderMethod  samplers/mod.rs:43-47 */
+typedef enum rt_render_method { RT_METHOD_NAIVE = 0, RT_METHOD_MIS = 1 } rt_render_method;
+
+typedef enum rt_output_layout {
+	RT_LAYOUT_FRAME = 0, /* width*height*3 floats, row-major, y down, RGB (SamplerProgress.current_image) */
+	RT_LAYOUT_SHARD = 1  /* only this shard's pixels, packed in work order (see rt_shard_pixel_order) */
+} rt_output_layout;
+
+/* RenderOptions (samplers/mod.rs:22-41) plus what the reference hard-codes or lacks:
+ * MAX_DEPTH / RUSSIAN_ROULETTE_THRESHOLD (integrators/mod.rs:7-8), a seed, a sample
+ * window for resume/progressive batches, and the tile sharding used across GPUs. */
+typedef struct rt_render_opts {
+	uint64_t width;
+	uint64_t height;
+	uint64_t samples_per_pixel; /* passes rendered by THIS call */
+	uint64_t sample_begin;      /* index of the first pass (0 for a fresh render) */
+	uint64_t seed;
+	int32_t render_method;  /* rt_render_method; reference default MIS (src/parameters.rs:37-38) */
+	uint32_t max_depth;     /* reference value 50 */
+	uint32_t rr_threshold;  /* reference value 3  */
+	uint32_t shard_index;   /* this GPU's shard, 0 <= shard_index < shard_count */
+	uint32_t shard_count;   /* 1 = whole image */
+	uint32_t tile_width;    /* shard granularity in pixels; 0 = default (8) */
+	uint32_t tile_height;   /* 0 = default (8) */
+	int32_t output_layout;  /* rt_output_layout */
+} rt_render_opts;
+
+void rt_render_opts_default(rt_render_opts *opts);
+
+/* One hit record = Hit + material + primitive index
+ * (rt_core/src/primitive.rs:3-16, the tuple Bvh::check_hit returns acceleration/mod.rs:265-298) */
+typedef struct rt_hit_record {
+	float t;
+	float point[3];
+	float error[3];
+	float normal[3];
+	float uv[2];
+	int32_t has_uv;
+	int32_t out;
+	uint32_t material;
+	uint32_t found;  /* check_hit: always 1; check_hit_index: 0 when the call returns None */
+	uint64_t index;  /* primitive index in BVH order; UINT64_MAX = sky (usize::MAX) */
+} rt_hit_record;
+
+/* A ray as handed to Ray::new(origin, direction, time)  rt_core/src/ray.rs:13-46 */
+typedef struct rt_ray_desc {
+	float origin[3];
+	float direction[3];
+} rt_ray_desc;
+
+/* Node { bounds, children, primitive_offset, number_primitives }  acceleration/mod.rs:331-336 */
+typedef struct rt_bvh_node {
+	float min[3];
+	float max[3];
+	int64_t children[2]; /* -1,-1 = None (leaf) */
+	uint64_t primitive_offset;
+	uint64_t number_primitives;
+} rt_bvh_node;
+
+typedef struct rt_scene rt_scene;
+
+/* ---- library ---- */
+const char *rt_last_error(void);
+uint32_t rt_abi_version(void);
+int rt_device_count(void);
+
+/* ---- SimpleCamera::new  camera.rs:20-54 (aspect is 16/9 in the loader: loader/src/misc.rs:15) ---- */
+int rt_camera_new(rt_camera *out, const float origin[3], const float lookat[3], const float vup[3],
+                  float fov_degrees, float aspect_ratio, float aperture, float focus_dist);
+
+/* ---- Bvh::new + upload: builds the BVH on the host exactly as acceleration/mod.rs:58-160 and
+ * acceleration/split.rs:78-210 do, builds the sky tables (textures/mod.rs:32-50,
+ * statistics/distributions.rs:12-99), and lays everything out in the HBM of `device`. ---- */
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/* introspection of what Bvh::new produced (for parity tests against the oracle) */
+int rt_scene_counts(const rt_scene *scene, uint64_t *n_nodes, uint64_t *n_primitives, uint64_t *n_lights);
+int rt_scene_get_nodes(const rt_scene *scene, rt_bvh_node *out, uint64_t capacity);
+/* primitive_order[i] = index in rt_scene_desc.primitives of the primitive at BVH slot i
+ * (the permutation sort_by_indices applies, acceleration/mod.rs:79-82) */
+int rt_scene_get_primitive_order(const rt_scene *scene, uint64_t *out, uint64_t capacity);
+int rt_scene_get_lights(const rt_scene *scene, uint64_t *out, uint64_t capacity); /* Bvh.lights :84-88 */
+
+/* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----
+ * Renders opts->samples_per_pixel passes and returns their running mean
+ * `mean += (pass - mean) / i`, i = 1..samples_per_pixel -- the accumulation the reference's
+ * callback performs on the host after every pass (src/main.rs:175-191) -- and the sum of
+ * the integrators' ray counters (SamplerProgress.rays_shot).  Blocking.
+ * out_rgb: HOST buffer, layout per opts->output_layout.  rays_shot may be NULL. */
+int rt_render(rt_scene *scene, const rt_camera *camera, const rt_render_opts *opts, float *out_rgb,
+              uint64_t *rays_shot);
+
+/* Same, asynchronous on a caller-supplied HIP stream, into DEVICE memory of the scene's GPU
+ * (d_out_rgb sized by rt_render_output_floats, d_rays_shot one uint64 or NULL).  No host sync. */
+int rt_render_device(rt_scene *scene, const rt_camera *camera, const rt_render_opts *opts, float *d_out_rgb,
+                     uint64_t *d_rays_shot, void *hip_stream);
+
+/* number of floats rt_render writes for these options (FRAME: w*h*3; SHARD: 3*owned pixels) */
+int rt_render_output_floats(const rt_render_opts *opts, uint64_t *n_floats);
+/* pixel indices (y*width+x) of the shard's pixels in the order RT_LAYOUT_SHARD packs them */
+int rt_shard_pixel_order(const rt_render_opts *opts, uint64_t *out, uint64_t capacity);
+
+/* Milliseconds the GPU spent in the render kernel of the most recent rt_render /
+ * rt_render_device on this scene, measured with HIP events on the launch stream
+ * (synchronises that stream).  The kernel's launch count is returned through n_launches. */
+int rt_last_kernel_ms(rt_scene *scene, float *ms, uint32_t *n_launches);
+
+/* ---- AccelerationStructure::check_hit / check_hit_index for a batch of rays
+ * (acceleration/mod.rs:226-298), run on the GPU; host buffers ---- */
+int rt_check_hit(rt_scene *scene, const rt_ray_desc *rays, uint64_t n_rays, rt_hit_record *out);
+int rt_check_hit_index(rt_scene *scene, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n_rays,
+                       rt_hit_record *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

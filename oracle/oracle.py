@@ -1,0 +1,255 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: importable only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under raytracing-rust_amd/ imports this module.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_pkg = importlib.import_module("raytracing-rust_amd")
+abi = _pkg.abi
+
+_LIB = None
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("rays", "node_tests", "sphere_tests", "triangle_tests", "closest_hits", "sky_ops", "rng_draws")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ora_last_error.restype = C.c_char_p
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError(f"oracle error {rc}: {lib().ora_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+def camera_new(origin, lookat, vup, fov, aspect_ratio, aperture, focus_dist):
+    cam = abi.Camera()
+    _check(lib().ora_camera_new(C.byref(cam), _f3(origin), _f3(lookat), _f3(vup), C.c_float(fov),
+                                C.c_float(aspect_ratio), C.c_float(aperture), C.c_float(focus_dist)))
+    return cam
+
+
+class Scene:
+    def __init__(self, scene_description):
+        self._desc = scene_description.desc()
+        self._h = C.c_void_p()
+        _check(lib().ora_scene_create(C.byref(self._desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ora_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().ora_scene_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def nodes(self):
+        n = self.counts()[0]
+        out = (abi.BvhNode * max(1, n))()
+        _check(lib().ora_scene_get_nodes(self._h, out, C.c_uint64(n)))
+        return np.frombuffer(bytes(out), dtype=NODE_DTYPE)[:n].copy()
+
+    def primitive_order(self):
+        n = self.counts()[1]
+        out = np.zeros(max(1, n), dtype=np.uint64)
+        _check(lib().ora_scene_get_primitive_order(self._h, _p(out, C.c_uint64), C.c_uint64(n)))
+        return out[:n]
+
+    def lights(self):
+        n = self.counts()[2]
+        out = np.zeros(max(1, n), dtype=np.uint64)
+        _check(lib().ora_scene_get_lights(self._h, _p(out, C.c_uint64), C.c_uint64(n)))
+        return out[:n]
+
+    def render(self, camera, opts, n_threads=None, want_counters=False):
+        if n_threads is None:
+            n_threads = os.cpu_count() or 1
+        out = np.zeros((opts.height, opts.width, 3), dtype=np.float32)
+        rays = C.c_uint64()
+        cnt = Counters()
+        _check(lib().ora_render(self._h, C.byref(camera), C.byref(opts), _p(out, C.c_float), C.byref(rays),
+                                C.c_uint32(n_threads), C.byref(cnt)))
+        if want_counters:
+            return out, rays.value, cnt.as_dict()
+        return out, rays.value
+
+    def check_hit(self, origins, directions):
+        rays = pack_rays(origins, directions)
+        n = rays.shape[0]
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        _check(lib().ora_check_hit(self._h, rays.ctypes.data_as(C.POINTER(abi.RayDesc)), C.c_uint64(n),
+                                   out.ctypes.data_as(C.POINTER(abi.HitRecord))))
+        return out
+
+    def check_hit_index(self, origins, directions, indices):
+        rays = pack_rays(origins, directions)
+        n = rays.shape[0]
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = np.zeros(n, dtype=HIT_DTYPE)
+        _check(lib().ora_check_hit_index(self._h, rays.ctypes.data_as(C.POINTER(abi.RayDesc)), _p(idx, C.c_uint64),
+                                         C.c_uint64(n), out.ctypes.data_as(C.POINTER(abi.HitRecord))))
+        return out
+
+    def integrate_ray(self, origin, direction, method, n_samples, seed=1, max_depth=50, rr_threshold=3,
+                      n_threads=None):
+        if n_threads is None:
+            n_threads = os.cpu_count() or 1
+        ray = abi.RayDesc()
+        ray.origin = _f3(origin)
+        ray.direction = _f3(direction)
+        out = (C.c_double * 3)()
+        _check(lib().ora_integrate_ray(self._h, C.byref(ray), C.c_int32(method), C.c_uint32(max_depth),
+                                       C.c_uint32(rr_threshold), C.c_uint64(seed), C.c_uint64(n_samples),
+                                       C.c_uint32(n_threads), out))
+        return np.array(list(out))
+
+    def sample_directions(self, which, n, seed=1, incoming=(0, 0, 1), normal=(0, 0, 1), alpha=0.0, prim_index=0):
+        out = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().ora_sample_directions(self._h, C.c_int32(which), _f3(incoming), _f3(normal), C.c_float(alpha),
+                                           C.c_uint64(prim_index), C.c_uint64(seed), C.c_uint64(n), _p(out, C.c_float)))
+        return out
+
+    def eval_pdfs(self, which, dirs, incoming=(0, 0, 1), normal=(0, 0, 1), alpha=0.0):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(dirs.shape[0], dtype=np.float32)
+        _check(lib().ora_eval_pdfs(self._h, C.c_int32(which), _f3(incoming), _f3(normal), C.c_float(alpha),
+                                   _p(dirs, C.c_float), C.c_uint64(dirs.shape[0]), _p(out, C.c_float)))
+        return out
+
+    def sky_tables(self, res_x, res_y):
+        rows = np.zeros((res_y, res_x + 1), dtype=np.float32)
+        marg = np.zeros(res_y + 1, dtype=np.float32)
+        _check(lib().ora_sky_tables(self._h, _p(rows, C.c_float), _p(marg, C.c_float)))
+        return rows, marg
+
+
+# numpy views of the ABI records
+HIT_DTYPE = np.dtype([("t", "<f4"), ("point", "<f4", 3), ("error", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2),
+                      ("has_uv", "<i4"), ("out", "<i4"), ("material", "<u4"), ("found", "<u4"), ("index", "<u8")])
+NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("children", "<i8", 2), ("primitive_offset", "<u8"),
+                       ("number_primitives", "<u8")])
+assert HIT_DTYPE.itemsize == C.sizeof(abi.HitRecord) and NODE_DTYPE.itemsize == C.sizeof(abi.BvhNode)
+
+
+def pack_rays(origins, directions):
+    o = np.asarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.asarray(directions, dtype=np.float32).reshape(-1, 3)
+    return np.ascontiguousarray(np.concatenate([o, d], axis=1))
+
+
+# ---- free functions for the unit / statistical tests ----
+def sample_directions_noscene(which, n, seed=1, incoming=(0, 0, 1), normal=(0, 0, 1), alpha=0.0):
+    out = np.zeros((n, 3), dtype=np.float32)
+    _check(lib().ora_sample_directions(None, C.c_int32(which), _f3(incoming), _f3(normal), C.c_float(alpha),
+                                       C.c_uint64(0), C.c_uint64(seed), C.c_uint64(n), _p(out, C.c_float)))
+    return out
+
+
+def eval_pdfs_noscene(which, dirs, incoming=(0, 0, 1), normal=(0, 0, 1), alpha=0.0):
+    dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(dirs.shape[0], dtype=np.float32)
+    _check(lib().ora_eval_pdfs(None, C.c_int32(which), _f3(incoming), _f3(normal), C.c_float(alpha),
+                               _p(dirs, C.c_float), C.c_uint64(dirs.shape[0]), _p(out, C.c_float)))
+    return out
+
+
+def detmath(which, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out = np.zeros_like(a)
+    _check(lib().ora_detmath_eval(C.c_int32(which), _p(a, C.c_float), _p(b, C.c_float), C.c_uint64(a.size),
+                                  _p(out, C.c_float)))
+    return out
+
+
+def rng_f32(seed, pixel, sample, n):
+    out = np.zeros(n, dtype=np.float32)
+    _check(lib().ora_rng_fill_f32(C.c_uint64(seed), C.c_uint64(pixel), C.c_uint64(sample), C.c_uint64(n),
+                                  _p(out, C.c_float)))
+    return out
+
+
+def rng_u32(seed, pixel, sample, n):
+    out = np.zeros(n, dtype=np.uint32)
+    _check(lib().ora_rng_fill_u32(C.c_uint64(seed), C.c_uint64(pixel), C.c_uint64(sample), C.c_uint64(n),
+                                  _p(out, C.c_uint32)))
+    return out
+
+
+def rng_below(seed, bound, n):
+    out = np.zeros(n, dtype=np.uint32)
+    _check(lib().ora_rng_fill_below(C.c_uint64(seed), C.c_uint32(bound), C.c_uint64(n), _p(out, C.c_uint32)))
+    return out
+
+
+def dist1d(values, n, seed=1):
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    idx = np.zeros(n, dtype=np.uint64)
+    pdf = np.zeros(values.size, dtype=np.float32)
+    cdf = np.zeros(values.size + 1, dtype=np.float32)
+    _check(lib().ora_dist1d_sample_many(_p(values, C.c_float), C.c_uint64(values.size), C.c_uint64(seed), C.c_uint64(n),
+                                        _p(idx, C.c_uint64), _p(pdf, C.c_float), _p(cdf, C.c_float)))
+    return idx, pdf, cdf
+
+
+def sort_by_indices(values, indices):
+    v = np.ascontiguousarray(values, dtype=np.uint64).copy()
+    i = np.ascontiguousarray(indices, dtype=np.uint64)
+    _check(lib().ora_sort_by_indices(_p(v, C.c_uint64), C.c_uint64(v.size), _p(i, C.c_uint64)))
+    return v
+
+
+def utility(which, a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.zeros_like(a)
+    _check(lib().ora_utility_eval(C.c_int32(which), _p(a, C.c_float), C.c_uint64(a.size), _p(out, C.c_float)))
+    return out
+
+
+def offset_ray(origin, normal, error, is_brdf=True):
+    out = (C.c_float * 3)()
+    _check(lib().ora_offset_ray(_f3(origin), _f3(normal), _f3(error), C.c_int32(1 if is_brdf else 0), out))
+    return np.array(list(out), dtype=np.float32)

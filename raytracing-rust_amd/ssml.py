@@ -1,0 +1,278 @@
+"""Minimal `.ssml` scene reader: feeds the reference's own scene files to the back end.
+
+Grammar restated from crates/loader/src/parser.rs:82-197 and the per-type defaults from
+crates/loader/src/{lib,misc,textures,materials,primitives,meshes}.rs:
+
+    file    = ["#ver1"] object*
+    object  = kind [name] "(" (key value NEWLINE)* ")"
+    kind    = camera | material | primitive | sky | texture | mesh
+    value   = 3 floats | 2 floats | 1 float | free text to end of line
+
+Load order (loader/src/lib.rs:218-240): textures (+ `__DEFAULT_TEX`), materials
+(+ `__DEFAULT_MAT`), camera, sky, primitives, meshes.
+"""
+import re
+
+import numpy as np
+
+from . import abi
+from .scene import SceneDescription
+
+_KINDS = ("camera", "material", "primitive", "sky", "texture", "mesh")
+_IDENT = r"[A-Za-z_][A-Za-z0-9_]*"
+_FLOAT = r"[+-]?(?:(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?|inf(?:inity)?|nan)"
+
+
+class SsmlError(ValueError):
+    pass
+
+
+def _parse_value(text):
+    """parser.rs:119-131: try 3 floats, then 2, then 1 (each `preceded(space0, double)`), else text."""
+    one = re.compile(r"[ \t]*(" + _FLOAT + r")", re.IGNORECASE)
+    for n in (3, 2, 1):
+        pos, got = 0, []
+        for _ in range(n):  # nom's `double` is greedy and never backtracks: take floats one at a time
+            m = one.match(text, pos)
+            if not m:
+                break
+            got.append(np.float32(float(m.group(1))))
+            pos = m.end()
+        if len(got) == n and text[pos:] == "":
+            return tuple(got)
+    return text.lstrip(" \t")
+
+
+def parse(src):
+    """-> list of (kind, name|None, {key: value}) in file order."""
+    pos = 0
+    n = len(src)
+
+    def skip_ws():
+        nonlocal pos
+        while pos < n and src[pos] in " \t\r\n":
+            pos += 1
+
+    skip_ws()
+    if src.startswith("#ver1", pos):
+        pos += 5
+    objects = []
+    while True:
+        skip_ws()
+        if pos >= n:
+            break
+        m = re.compile(r"(" + "|".join(_KINDS) + r")").match(src, pos)
+        if not m:
+            raise SsmlError(f"expected object kind at offset {pos}")
+        kind = m.group(1)
+        pos = m.end()
+        name = None
+        m = re.compile(r"[ \t]+(" + _IDENT + r")").match(src, pos)
+        if m:
+            name = m.group(1)
+            pos = m.end()
+        skip_ws()
+        if pos >= n or src[pos] != "(":
+            raise SsmlError(f"expected '(' after {kind}")
+        pos += 1
+        skip_ws()
+        values = {}
+        while True:
+            m = re.compile(r"[ \t]*(" + _IDENT + r")[ \t]+([^\r\n]*)(\r?\n)").match(src, pos)
+            if not m:
+                break
+            values[m.group(1)] = _parse_value(m.group(2))  # HashMap: a repeated key keeps the last value
+            pos = m.end()
+        skip_ws()
+        if pos >= n or src[pos] != ")":
+            raise SsmlError(f"expected ')' closing {kind} at offset {pos}")
+        pos += 1
+        objects.append((kind, name, values))
+    return objects
+
+
+class _Props:
+    """Properties accessors with the loader's auto-cast (loader/src/lib.rs:103-178)."""
+
+    def __init__(self, values):
+        self.v = values
+
+    def vec3(self, key):
+        x = self.v.get(key)
+        if isinstance(x, tuple) and len(x) == 3:
+            return x
+        if isinstance(x, tuple) and len(x) == 1:
+            return (x[0], x[0], x[0])
+        return None
+
+    def vec2(self, key):
+        x = self.v.get(key)
+        if isinstance(x, tuple) and len(x) == 2:
+            return x
+        if isinstance(x, tuple) and len(x) == 1:
+            return (x[0], x[0])
+        return None
+
+    def float(self, key):
+        x = self.v.get(key)
+        if isinstance(x, tuple) and len(x) == 1:
+            return x[0]
+        return None
+
+    def text(self, key):
+        x = self.v.get(key)
+        return x if isinstance(x, str) else None
+
+
+def _or(value, default):
+    return default if value is None else value
+
+
+def _f32_as_usize(x):
+    x = float(x)
+    if not x > 0:
+        return 0
+    return int(x)
+
+
+class LoadedScene:
+    def __init__(self, scene, camera_params):
+        self.scene = scene  # SceneDescription
+        self.camera_params = camera_params  # dict for rt_camera_new
+
+
+def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0):
+    objects = parse(src)
+    sc = SceneDescription(split_type)
+    tex_by_name, mat_by_name = {}, {}
+
+    # ---- textures (loader/src/textures.rs) ----
+    for kind, name, values in objects:
+        if kind != "texture":
+            continue
+        p = _Props(values)
+        ttype = p.text("type")
+        if ttype is None:
+            raise SsmlError("missing required type for texture")
+        if ttype == "solid":
+            idx = sc.solid(_or(p.vec3("colour"), (0.5, 0.5, 0.5)))
+        elif ttype == "lerp":
+            idx = sc.lerp(_or(p.vec3("primary"), (1, 1, 1)), _or(p.vec3("secondary"), (0, 0, 0)))
+        elif ttype == "checkered":
+            idx = sc.checkered(_or(p.vec3("primary"), (1, 1, 1)), _or(p.vec3("secondary"), (0, 0, 0)))
+        elif ttype == "perlin":
+            ran_vecs, perm = perlin_tables(perlin_seed)
+            idx = sc.perlin(ran_vecs, perm)
+        elif ttype == "image":
+            raise SsmlError("image textures need a decoder; pass decoded pixels through SceneDescription.image")
+        else:
+            raise SsmlError(f"required a known value for texture type, found '{ttype}'")
+        if name is not None:
+            tex_by_name[name] = idx
+    tex_by_name["__DEFAULT_TEX"] = sc.solid((1, 1, 1))  # loader/src/lib.rs:354-368
+
+    def tex_of(p):
+        t = p.text("texture")
+        return tex_by_name.get(t, tex_by_name["__DEFAULT_TEX"]) if t is not None else tex_by_name["__DEFAULT_TEX"]
+
+    # ---- materials (loader/src/materials.rs) ----
+    def load_material(values):
+        p = _Props(values)
+        mtype = p.text("type")
+        if mtype is None:
+            raise SsmlError("missing required type for material")
+        if mtype == "lambertian":
+            return sc.lambertian(tex_of(p), _or(p.float("albedo"), 0.5))
+        if mtype == "emissive":
+            return sc.emissive(tex_of(p), _or(p.float("strength"), 1.5))
+        if mtype == "reflect":
+            return sc.reflect(tex_of(p), _or(p.float("fuzz"), 0.1))
+        if mtype == "refract":
+            return sc.refract(tex_of(p), _or(p.float("eta"), 1.5))
+        if mtype == "trowbridge_reitz":
+            return sc.trowbridge_reitz(tex_of(p), _or(p.float("alpha"), 0.5), _or(p.vec3("ior"), (1, 1, 1)),
+                                       _or(p.float("metallic"), 0.0))
+        raise SsmlError(f"required a known value for material type, found '{mtype}'")
+
+    for kind, name, values in objects:
+        if kind == "material":
+            idx = load_material(values)
+            if name is not None:
+                mat_by_name[name] = idx
+    mat_by_name["__DEFAULT_MAT"] = load_material(  # loader/src/lib.rs:382-397
+        {"type": "lambertian", "texture": "__DEFAULT_TEX", "albedo": (np.float32(0.25),)})
+
+    def mat_of(p):
+        m = p.text("material")
+        return mat_by_name.get(m, mat_by_name["__DEFAULT_MAT"]) if m is not None else mat_by_name["__DEFAULT_MAT"]
+
+    # ---- camera (loader/src/misc.rs:6-18) ----
+    cams = [v for k, _, v in objects if k == "camera"]
+    if not cams:
+        raise SsmlError("missing required camera object")
+    p = _Props(cams[0])
+    camera_params = dict(
+        origin=_or(p.vec3("origin"), (3.0, 0.0, 0.0)),
+        lookat=_or(p.vec3("lookat"), (0.0, 0.0, 0.0)),
+        vup=_or(p.vec3("vup"), (0.0, 1.0, 0.0)),
+        fov=_or(p.float("fov"), 40.0),
+        aspect_ratio=float(np.float32(16.0) / np.float32(9.0)),
+        aperture=_or(p.float("aperture"), 0.0),
+        focus_dist=_or(p.float("focus_dis"), 10.0),
+    )
+
+    # ---- sky (loader/src/misc.rs:20-38) ----
+    skies = [v for k, _, v in objects if k == "sky"]
+    p = _Props(skies[0] if skies else {})
+    res = _or(p.vec2("sampler_res"), (100.0, 100.0))
+    sc.set_sky(tex_of(p), (_f32_as_usize(res[0]), _f32_as_usize(res[1])))
+
+    # ---- primitives (loader/src/primitives.rs) ----
+    for kind, _, values in objects:
+        if kind != "primitive":
+            continue
+        p = _Props(values)
+        ptype = p.text("type")
+        if ptype is None:
+            raise SsmlError("missing required type for primitive")
+        if ptype != "sphere":
+            raise SsmlError(f"required a known value for primitive type, found '{ptype}'")
+        centre = p.vec3("centre")
+        if centre is None:
+            raise SsmlError("expected centre on sphere, found nothing")
+        sc.sphere(centre, _or(p.float("radius"), 1.0), mat_of(p))
+
+    # ---- meshes (loader/src/meshes.rs) ----
+    for kind, _, values in objects:
+        if kind != "mesh":
+            continue
+        p = _Props(values)
+        mtype = p.text("type")
+        if mtype is None:
+            raise SsmlError("missing required type for mesh")
+        if mtype == "aacuboid":
+            p1, p2 = p.vec3("point_one"), p.vec3("point_two")
+            if p1 is None or p2 is None:
+                raise SsmlError("expected point_one and point_two on aacuboid")
+            sc.aacuboid(p1, p2, mat_of(p))
+        elif mtype == "mesh":
+            raise SsmlError("Wavefront OBJ meshes are not supported yet (SURVEY 8(f1))")
+        else:
+            raise SsmlError(f"required a known value for mesh type, found '{mtype}'")
+
+    return LoadedScene(sc, camera_params)
+
+
+def load_file(path, **kw):
+    with open(path, "r") as f:
+        return load_str(f.read(), **kw)
+
+
+def perlin_tables(seed=0):
+    """Perlin::new draws its tables from thread_rng (textures/mod.rs:91-152); here they come from
+    a seeded numpy generator so a scene file maps to one fixed texture."""
+    rng = np.random.default_rng(seed)
+    r = rng.uniform(-1.0, 1.0, size=256).astype(np.float32)
+    ran_vecs = np.repeat(r[:, None], 3, axis=1)  # gen_range(-1.0..1.0) * Vec3::one()
+    perm = np.stack([rng.permutation(256) for _ in range(3)]).astype(np.uint32)
+    return ran_vecs, perm
