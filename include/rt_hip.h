@@ -240,6 +240,10 @@ int rt_scene_get_nodes(const rt_scene *scene, rt_bvh_node *out, uint64_t capacit
  * (the permutation sort_by_indices applies, acceleration/mod.rs:79-82) */
 int rt_scene_get_primitive_order(const rt_scene *scene, uint64_t *out, uint64_t capacity);
 int rt_scene_get_lights(const rt_scene *scene, uint64_t *out, uint64_t capacity); /* Bvh.lights :84-88 */
+/* How the BVH is walked: -1 automatic (default), 0 exhaustive = every AABB-hit node and every
+ * primitive of every hit leaf, the reference's own amount of work (acceleration/mod.rs:199-224,
+ * 270-293), 1 = near-first with t-pruning.  All modes return the same hits. */
+int rt_scene_set_traversal(rt_scene *scene, int mode);
 
 /* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----
  * Renders opts->samples_per_pixel passes and returns their running mean

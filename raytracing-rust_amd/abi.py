@@ -194,6 +194,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_nodes",
     "rt_scene_get_primitive_order",
     "rt_scene_get_lights",
+    "rt_scene_set_traversal",
     "rt_render",
     "rt_render_device",
     "rt_render_output_floats",

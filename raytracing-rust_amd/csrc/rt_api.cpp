@@ -1,0 +1,507 @@
+// rt_api.cpp -- the extern "C" boundary of librt_hip.so (include/rt_hip.h).
+//
+// Owns device memory for one scene (rt_scene), turns RenderOptions-style arguments into one
+// persistent kernel launch (rt_render.hip) and reports errors as codes + rt_last_error().
+// There is NO CPU fallback: without a HIP device every compute entry point fails with
+// RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_build.h"
+#include "rt_types.h"
+
+namespace rt {
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_block);
+hipError_t render_occupancy(int method, bool prune, bool sky_lds, size_t lds_bytes, int *blocks_per_cu);
+hipError_t launch_render(int method, bool prune, bool sky_lds, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+                         const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
+                         unsigned long long *rays_shot, uint32_t *work_counter);
+hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
+hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
+                                  uint64_t n, void *out);
+} // namespace rt
+
+using namespace rt;
+
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string &msg)
+{
+	g_error = msg;
+	return code;
+}
+static int hip_fail(hipError_t e, const char *what)
+{
+	g_error = std::string(what) + ": " + hipGetErrorString(e);
+	return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP;
+}
+#define HIP_TRY(expr)                       \
+	do {                                    \
+		hipError_t e_ = (expr);             \
+		if (e_ != hipSuccess)               \
+			return hip_fail(e_, #expr);     \
+	} while (0)
+
+struct rt_scene {
+	int device = 0;
+	HostScene host;
+	DevScene dev{};
+	std::vector<void *> allocations;
+	hipStream_t stream = nullptr; // used by the blocking entry points
+	uint32_t *d_work_counter = nullptr;
+	unsigned long long *d_rays = nullptr;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	bool timed = false;
+	uint32_t n_launches = 0;
+	int n_cus = 0;
+	int traversal_mode = -1; // -1 auto, 0 exhaustive (reference order of work), 1 pruned
+	size_t max_lds = 65536;
+};
+
+template <class T> static int upload(rt_scene *s, const T *src, size_t count, const T **dst)
+{
+	void *p = nullptr;
+	const size_t bytes = (count ? count : 1) * sizeof(T);
+	HIP_TRY(hipMalloc(&p, bytes));
+	s->allocations.push_back(p);
+	if (count)
+		HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+	*dst = static_cast<const T *>(p);
+	return RT_OK;
+}
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+void rt_render_opts_default(rt_render_opts *o)
+{
+	if (!o)
+		return;
+	std::memset(o, 0, sizeof *o);
+	o->width = 1920; // RenderOptions::default  samplers/mod.rs:31-41
+	o->height = 1080;
+	o->samples_per_pixel = 128;
+	o->render_method = RT_METHOD_MIS;
+	o->max_depth = 50;   // integrators/mod.rs:7
+	o->rr_threshold = 3; // integrators/mod.rs:8
+	o->shard_count = 1;
+	o->output_layout = RT_LAYOUT_FRAME;
+}
+
+int rt_camera_new(rt_camera *out, const float origin[3], const float lookat[3], const float vup[3], float fov_degrees,
+                  float aspect_ratio, float aperture, float focus_dist)
+{
+	if (!out || !origin || !lookat || !vup)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	camera_new(out, origin, lookat, vup, fov_degrees, aspect_ratio, aperture, focus_dist);
+	return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *s)
+{
+	if (!s)
+		return;
+	(void)hipSetDevice(s->device);
+	for (void *p : s->allocations)
+		(void)hipFree(p);
+	if (s->ev_start)
+		(void)hipEventDestroy(s->ev_start);
+	if (s->ev_stop)
+		(void)hipEventDestroy(s->ev_stop);
+	if (s->stream)
+		(void)hipStreamDestroy(s->stream);
+	delete s;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
+{
+	if (!desc || !out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	*out = nullptr;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+		return fail(RT_ERR_NO_DEVICE, "no HIP device: the rt_hip back end has no CPU fallback");
+	if (device < 0 || device >= n_dev)
+		return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+
+	rt_scene *s = new rt_scene();
+	s->device = device;
+	std::string err;
+	int rc = build_host_scene(desc, s->host, err);
+	if (rc != RT_OK) {
+		delete s;
+		return fail(rc, err);
+	}
+	HostScene &h = s->host;
+
+	auto bail = [&](int code) {
+		rt_scene_destroy(s);
+		return code;
+	};
+	if (hipSetDevice(device) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipSetDevice failed"));
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
+	s->n_cus = prop.multiProcessorCount;
+	s->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+
+	DevScene &D = s->dev;
+	std::memset(&D, 0, sizeof D);
+	// per-texture payloads first, so the texture records can point at them
+	for (size_t i = 0; i < h.textures.size(); ++i) {
+		if (!h.tex_images[i].empty()) {
+			if ((rc = upload(s, h.tex_images[i].data(), h.tex_images[i].size(), &h.textures[i].image)) != RT_OK)
+				return bail(rc);
+		}
+		if (!h.tex_perlin_vecs[i].empty()) {
+			if ((rc = upload(s, h.tex_perlin_vecs[i].data(), h.tex_perlin_vecs[i].size(), &h.textures[i].perlin_vecs)) != RT_OK)
+				return bail(rc);
+			if ((rc = upload(s, h.tex_perlin_perm[i].data(), h.tex_perlin_perm[i].size(), &h.textures[i].perlin_perm)) != RT_OK)
+				return bail(rc);
+		}
+	}
+	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.prim_rank.data(), h.prim_rank.size(), &D.prim_rank)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.materials.data(), h.materials.size(), &D.materials)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.textures.data(), h.textures.size(), &D.textures)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
+	const float *d_sky = nullptr;
+	if ((rc = upload(s, h.sky_cdf.data(), h.sky_cdf.size(), &d_sky)) != RT_OK) return bail(rc);
+
+	D.n_nodes = (uint32_t)h.dev_nodes.size();
+	D.n_prims = (uint32_t)h.dev_prims.size();
+	D.n_lights = (uint32_t)h.dev_lights.size();
+	D.n_materials = (uint32_t)h.materials.size();
+	D.n_textures = (uint32_t)h.textures.size();
+	D.root_is_leaf = h.root_is_leaf ? 1 : 0;
+	std::memcpy(D.root_min, h.root_min, sizeof D.root_min);
+	std::memcpy(D.root_max, h.root_max, sizeof D.root_max);
+	D.stack_depth = h.stack_depth;
+	D.has_triangles = h.has_triangles ? 1u : 0u;
+	D.sky.texture = h.sky.texture;
+	D.sky.material = h.sky.material;
+	D.sky.res_x = h.sky.sampler_res_x;
+	D.sky.res_y = h.sky.sampler_res_y;
+	D.sky.row_cdf = d_sky;
+	D.sky.marginal_cdf = d_sky + (size_t)h.sky.sampler_res_y * (h.sky.sampler_res_x + 1u);
+
+	void *p = nullptr;
+	if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc work counter"));
+	s->allocations.push_back(p);
+	s->d_work_counter = static_cast<uint32_t *>(p);
+	if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc rays"));
+	s->allocations.push_back(p);
+	s->d_rays = static_cast<unsigned long long *>(p);
+	if (hipStreamCreate(&s->stream) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
+	if (hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
+		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
+		if (std::strcmp(e, "pruned") == 0) s->traversal_mode = 1;
+	}
+	*out = s;
+	return RT_OK;
+}
+
+int rt_scene_set_traversal(rt_scene *s, int mode)
+{
+	if (!s || mode < -1 || mode > 1)
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	s->traversal_mode = mode;
+	return RT_OK;
+}
+
+int rt_scene_counts(const rt_scene *s, uint64_t *n_nodes, uint64_t *n_primitives, uint64_t *n_lights)
+{
+	if (!s)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null scene");
+	if (n_nodes) *n_nodes = s->host.nodes.size();
+	if (n_primitives) *n_primitives = s->host.primitive_order.size();
+	if (n_lights) *n_lights = s->host.lights.size();
+	return RT_OK;
+}
+int rt_scene_get_nodes(const rt_scene *s, rt_bvh_node *out, uint64_t capacity)
+{
+	if (!s || !out || capacity < s->host.nodes.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	for (size_t i = 0; i < s->host.nodes.size(); ++i) {
+		const HostNode &n = s->host.nodes[i];
+		std::memcpy(out[i].min, n.min, 12);
+		std::memcpy(out[i].max, n.max, 12);
+		out[i].children[0] = n.child[0];
+		out[i].children[1] = n.child[1];
+		out[i].primitive_offset = n.primitive_offset;
+		out[i].number_primitives = n.number_primitives;
+	}
+	return RT_OK;
+}
+int rt_scene_get_primitive_order(const rt_scene *s, uint64_t *out, uint64_t capacity)
+{
+	if (!s || !out || capacity < s->host.primitive_order.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.primitive_order.data(), s->host.primitive_order.size() * sizeof(uint64_t));
+	return RT_OK;
+}
+int rt_scene_get_lights(const rt_scene *s, uint64_t *out, uint64_t capacity)
+{
+	if (!s || !out || capacity < s->host.lights.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.lights.data(), s->host.lights.size() * sizeof(uint64_t));
+	return RT_OK;
+}
+
+} // extern "C"
+
+// ---- render ----
+namespace {
+
+struct ShardGeometry {
+	uint32_t tile_w, tile_h, tiles_x, tiles_y;
+	uint64_t n_tiles_owned, n_work;
+};
+
+int shard_geometry(const rt_render_opts *o, ShardGeometry &g)
+{
+	if (!o)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null options");
+	if (o->width < 2 || o->height < 2)
+		return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be >= 2 (u and v divide by W-1 and H-1)");
+	if (o->width * o->height >= (1ull << 31))
+		return fail(RT_ERR_UNSUPPORTED, "image larger than 2^31 pixels");
+	if (o->shard_count == 0 || o->shard_index >= o->shard_count)
+		return fail(RT_ERR_INVALID_ARGUMENT, "shard_index must be < shard_count and shard_count >= 1");
+	g.tile_w = o->tile_width ? o->tile_width : 8;
+	g.tile_h = o->tile_height ? o->tile_height : 8;
+	g.tiles_x = (uint32_t)((o->width + g.tile_w - 1) / g.tile_w);
+	g.tiles_y = (uint32_t)((o->height + g.tile_h - 1) / g.tile_h);
+	const uint64_t n_tiles = (uint64_t)g.tiles_x * g.tiles_y;
+	g.n_tiles_owned = n_tiles > o->shard_index ? (n_tiles - o->shard_index + o->shard_count - 1) / o->shard_count : 0;
+	g.n_work = g.n_tiles_owned * g.tile_w * g.tile_h;
+	return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_render_output_floats(const rt_render_opts *o, uint64_t *n_floats)
+{
+	ShardGeometry g;
+	int rc = shard_geometry(o, g);
+	if (rc != RT_OK)
+		return rc;
+	if (!n_floats)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	*n_floats = o->output_layout == RT_LAYOUT_SHARD ? g.n_work * 3 : o->width * o->height * 3;
+	return RT_OK;
+}
+
+int rt_shard_pixel_order(const rt_render_opts *o, uint64_t *out, uint64_t capacity)
+{
+	ShardGeometry g;
+	int rc = shard_geometry(o, g);
+	if (rc != RT_OK)
+		return rc;
+	if (!out || capacity < g.n_work)
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	const uint32_t tile_pixels = g.tile_w * g.tile_h;
+	for (uint64_t w = 0; w < g.n_work; ++w) { // same mapping as work_to_pixel() in rt_render.hip
+		const uint64_t k = w / tile_pixels, in = w % tile_pixels;
+		const uint64_t tile = o->shard_index + k * o->shard_count;
+		const uint64_t ty = tile / g.tiles_x, tx = tile % g.tiles_x;
+		const uint64_t x = tx * g.tile_w + in % g.tile_w, y = ty * g.tile_h + in / g.tile_w;
+		out[w] = (x < o->width && y < o->height) ? y * o->width + x : UINT64_MAX; // UINT64_MAX: edge-tile padding
+	}
+	return RT_OK;
+}
+
+int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, float *d_out_rgb, uint64_t *d_rays_shot,
+                     void *hip_stream)
+{
+	if (!s || !camera || !o || !d_out_rgb)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	ShardGeometry g;
+	int rc = shard_geometry(o, g);
+	if (rc != RT_OK)
+		return rc;
+	if (o->render_method != RT_METHOD_NAIVE && o->render_method != RT_METHOD_MIS)
+		return fail(RT_ERR_INVALID_ARGUMENT, "unknown render method");
+	if (o->samples_per_pixel == 0 || o->samples_per_pixel >= (1ull << 32))
+		return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be in [1, 2^32)");
+	if (o->output_layout != RT_LAYOUT_FRAME && o->output_layout != RT_LAYOUT_SHARD)
+		return fail(RT_ERR_INVALID_ARGUMENT, "unknown output layout");
+	HIP_TRY(hipSetDevice(s->device));
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+	DevRenderParams P;
+	std::memset(&P, 0, sizeof P);
+	P.width = (uint32_t)o->width;
+	P.height = (uint32_t)o->height;
+	P.spp = (uint32_t)o->samples_per_pixel;
+	P.sample_begin_lo = (uint32_t)o->sample_begin;
+	P.sample_begin_hi = (uint32_t)(o->sample_begin >> 32);
+	P.seed_lo = (uint32_t)o->seed;
+	P.seed_hi = (uint32_t)(o->seed >> 32);
+	P.max_depth = o->max_depth;
+	P.rr_threshold = o->rr_threshold;
+	P.shard_index = o->shard_index;
+	P.shard_count = o->shard_count;
+	P.tile_w = g.tile_w;
+	P.tile_h = g.tile_h;
+	P.tiles_x = g.tiles_x;
+	P.tiles_y = g.tiles_y;
+	P.n_work = (uint32_t)g.n_work;
+	P.shard_layout = o->output_layout == RT_LAYOUT_SHARD ? 1 : 0;
+
+	// traversal: exhaustive (the reference's own amount of work) for tiny trees where pruning cannot
+	// pay, t-pruned otherwise; both select the same winner (rt_intersect.h)
+	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > 32u : s->traversal_mode == 1;
+	P.prune = prune ? 1 : 0;
+
+	const bool samplable = (s->dev.sky.res_x | s->dev.sky.res_y) != 0u;
+	const size_t sky_bytes = samplable ? ((size_t)s->dev.sky.res_y * (s->dev.sky.res_x + 1u) + s->dev.sky.res_y + 1u) * 4 : 0;
+	const bool sky_lds = samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024;
+	P.sky_in_lds = sky_lds ? 1u : 0u;
+	const size_t lds_bytes = render_lds_bytes(s->dev, sky_lds, 4);
+	if (lds_bytes > s->max_lds)
+		return fail(RT_ERR_UNSUPPORTED, "traversal stacks + sky tables exceed the LDS of one CU");
+
+	int blocks_per_cu = 0;
+	HIP_TRY(render_occupancy(o->render_method, prune, sky_lds, lds_bytes, &blocks_per_cu));
+	if (blocks_per_cu < 1)
+		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
+	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
+	const uint64_t blocks_needed = (g.n_work + 255) / 256;
+	if (n_blocks > blocks_needed)
+		n_blocks = blocks_needed ? blocks_needed : 1;
+
+	if (o->output_layout == RT_LAYOUT_FRAME && o->shard_count > 1)
+		HIP_TRY(hipMemsetAsync(d_out_rgb, 0, o->width * o->height * 3 * sizeof(float), stream));
+	if (o->output_layout == RT_LAYOUT_SHARD)
+		HIP_TRY(hipMemsetAsync(d_out_rgb, 0, g.n_work * 3 * sizeof(float), stream));
+	HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+	if (d_rays_shot)
+		HIP_TRY(hipMemsetAsync(d_rays_shot, 0, sizeof(uint64_t), stream));
+
+	DevCamera cam;
+	std::memcpy(cam.origin, camera->origin, 12);
+	std::memcpy(cam.lower_left, camera->lower_left, 12);
+	std::memcpy(cam.horizontal, camera->horizontal, 12);
+	std::memcpy(cam.vertical, camera->vertical, 12);
+
+	HIP_TRY(hipEventRecord(s->ev_start, stream));
+	HIP_TRY(launch_render(o->render_method, prune, sky_lds, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, d_out_rgb,
+	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
+	HIP_TRY(hipEventRecord(s->ev_stop, stream));
+	s->timed = true;
+	s->n_launches = 1;
+	return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, float *out_rgb, uint64_t *rays_shot)
+{
+	if (!s || !camera || !o || !out_rgb)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	uint64_t n_floats = 0;
+	int rc = rt_render_output_floats(o, &n_floats);
+	if (rc != RT_OK)
+		return rc;
+	HIP_TRY(hipSetDevice(s->device));
+	float *d_out = nullptr;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), n_floats * sizeof(float)));
+	rc = rt_render_device(s, camera, o, d_out, reinterpret_cast<uint64_t *>(s->d_rays), s->stream);
+	if (rc == RT_OK) {
+		hipError_t e = hipMemcpyAsync(out_rgb, d_out, n_floats * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+		if (e == hipSuccess && rays_shot)
+			e = hipMemcpyAsync(rays_shot, s->d_rays, sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(s->stream);
+		if (e != hipSuccess)
+			rc = hip_fail(e, "render");
+	}
+	(void)hipFree(d_out);
+	return rc;
+}
+
+int rt_last_kernel_ms(rt_scene *s, float *ms, uint32_t *n_launches)
+{
+	if (!s || !ms)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (!s->timed)
+		return fail(RT_ERR_INVALID_ARGUMENT, "no render has been launched on this scene");
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipEventSynchronize(s->ev_stop));
+	HIP_TRY(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
+	if (n_launches)
+		*n_launches = s->n_launches;
+	return RT_OK;
+}
+
+// ---- batch hit queries ----
+static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n, rt_hit_record *out)
+{
+	if (!s || !rays || !out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (n == 0)
+		return RT_OK;
+	if (object_index)
+		for (uint64_t i = 0; i < n; ++i)
+			if (object_index[i] >= s->dev.n_prims)
+				return fail(RT_ERR_INVALID_ARGUMENT, "object index out of range");
+	HIP_TRY(hipSetDevice(s->device));
+	void *d_rays = nullptr, *d_out = nullptr, *d_idx = nullptr;
+	HIP_TRY(hipMalloc(&d_rays, n * sizeof(rt_ray_desc)));
+	hipError_t e = hipMalloc(&d_out, n * sizeof(rt_hit_record));
+	if (e == hipSuccess && object_index)
+		e = hipMalloc(&d_idx, n * sizeof(uint64_t));
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray_desc), hipMemcpyHostToDevice, s->stream);
+	if (e == hipSuccess && object_index)
+		e = hipMemcpyAsync(d_idx, object_index, n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream);
+	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > 32u : s->traversal_mode == 1;
+	if (e == hipSuccess)
+		e = object_index ? launch_check_hit_index(prune, s->stream, s->dev, d_rays, d_idx, n, d_out)
+		                 : launch_check_hit(prune, s->stream, s->dev, d_rays, n, d_out);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(out, d_out, n * sizeof(rt_hit_record), hipMemcpyDeviceToHost, s->stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(s->stream);
+	(void)hipFree(d_rays);
+	(void)hipFree(d_out);
+	(void)hipFree(d_idx);
+	if (e != hipSuccess)
+		return hip_fail(e, "check_hit");
+	return RT_OK;
+}
+
+int rt_check_hit(rt_scene *s, const rt_ray_desc *rays, uint64_t n_rays, rt_hit_record *out)
+{
+	return check_common(s, rays, nullptr, n_rays, out);
+}
+int rt_check_hit_index(rt_scene *s, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n_rays, rt_hit_record *out)
+{
+	if (!object_index)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	return check_common(s, rays, object_index, n_rays, out);
+}
+
+} // extern "C"

@@ -1,0 +1,51 @@
+// rt_build.h -- host-side scene build: Bvh::new of the reference plus the re-layout for HBM.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_types.h"
+
+namespace rt {
+
+// Node of acceleration/mod.rs:331-336, kept on the host for rt_scene_get_nodes()
+struct HostNode {
+	float min[3], max[3];
+	int64_t child[2]; // -1 = None
+	uint64_t primitive_offset, number_primitives;
+};
+
+struct HostScene {
+	// what Bvh::new produces
+	std::vector<HostNode> nodes;
+	std::vector<uint64_t> primitive_order; // slot -> index in rt_scene_desc.primitives
+	std::vector<uint64_t> lights;          // Bvh.lights (slots)
+	// device images
+	std::vector<DevNode> dev_nodes;
+	std::vector<DevPrim> dev_prims;
+	std::vector<DevShade> dev_shade;
+	std::vector<uint32_t> prim_rank;
+	std::vector<uint32_t> dev_lights;
+	std::vector<DevMaterial> materials;
+	std::vector<DevTexture> textures;            // image / perlin pointers are patched after upload
+	std::vector<std::vector<float>> tex_images;  // per texture: decoded pixels (may be empty)
+	std::vector<std::vector<float>> tex_perlin_vecs;
+	std::vector<std::vector<uint32_t>> tex_perlin_perm;
+	std::vector<float> sky_cdf;                  // rows (res_y * (res_x+1)) then marginal (res_y+1)
+	rt_sky_desc sky;
+	bool root_is_leaf = false;
+	float root_min[3], root_max[3];
+	uint32_t stack_depth = 2;
+	bool has_triangles = false;
+};
+
+// returns RT_OK or an rt_status; `err` receives the message
+int build_host_scene(const rt_scene_desc *desc, HostScene &out, std::string &err);
+
+// SimpleCamera::new  camera.rs:20-54
+void camera_new(rt_camera *out, const float origin[3], const float lookat[3], const float vup[3], float fov,
+                float aspect_ratio, float aperture, float focus_dist);
+
+} // namespace rt

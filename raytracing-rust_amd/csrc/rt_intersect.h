@@ -1,0 +1,460 @@
+// rt_intersect.h -- device rays, the AABB slab test, ray/sphere and ray/triangle intersection and
+// BVH traversal for gfx950.
+//
+// What is computed follows the reference exactly (same predicates, same operation order):
+//   Ray::new                      rt_core/src/ray.rs:13-46
+//   AABB::does_int                acceleration/aabb.rs:22-57
+//   Sphere::get_int               primitives/sphere.rs:34-105
+//   triangle_intersection         primitives/triangle.rs:105-216
+//   Bvh::check_hit / check_hit_index   acceleration/mod.rs:226-298
+// HOW the tree is walked does not: the reference collects every AABB-hit leaf breadth-first into a
+// heap Vec and then tests them all (mod.rs:199-224).  Here each lane walks depth-first with a
+// per-lane stack in LDS, two child boxes per 64-byte node fetch, near child first, optional
+// t-pruning.  The reference's result is "smallest t > 0; among equal t the primitive that comes
+// first in BFS-leaf order" (strict `<` at mod.rs:282); the same winner is selected here by
+// comparing (t, prim_rank) where prim_rank is the primitive's position in that BFS order.
+#pragma once
+
+#include "rt_types.h"
+
+namespace rt {
+
+struct Ray {
+	V3 o, d, inv, shear;
+};
+
+// Ray::new  ray.rs:13-46 (time is carried nowhere: it is never read on the render path)
+__device__ __forceinline__ Ray ray_new(V3 origin, V3 direction)
+{
+	Ray r;
+	direction = direction / mag(direction);
+	const float ax = fabsf(direction.x), ay = fabsf(direction.y), az = fabsf(direction.z);
+	// max_axis 0 (x dominant) and 1 (y dominant) BOTH swap x<->z (ray.rs:26-33)
+	const bool swap = (ax > ay && ax > az) || (ay > az);
+	const float sx = swap ? direction.z : direction.x;
+	const float sz = swap ? direction.x : direction.z;
+	r.o = origin;
+	r.d = direction;
+	r.inv = v3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+	r.shear = v3(-sx / sz, -direction.y / sz, 1.0f / sz);
+	return r;
+}
+__device__ __forceinline__ bool ray_swaps_xz(const Ray &r) // Axis::get_max_abs_axis + swap_z  primitives/mod.rs:62-82
+{
+	const float ax = fabsf(r.d.x), ay = fabsf(r.d.y), az = fabsf(r.d.z);
+	return (ax > ay && ax > az) || (ay > az);
+}
+
+// AABB::does_int  aabb.rs:22-57.  Returns the reference's predicate; tmin_out is the entry
+// distance (used only for ordering / pruning).
+__device__ __forceinline__ bool aabb_does_int(const float bmin[3], const float bmax[3], const Ray &r, float &tmin_out)
+{
+	constexpr float widen = 1.0f + 2.0f * gamma_n(3);
+	float t1 = (bmin[0] - r.o.x) * r.inv.x;
+	float t2 = (bmax[0] - r.o.x) * r.inv.x;
+	if (t1 > t2) { const float s = t1; t1 = t2; t2 = s; }
+	t2 *= widen;
+	float tmin = fmin_(t1, t2);
+	float tmax = fmax_(t1, t2);
+
+	t1 = (bmin[1] - r.o.y) * r.inv.y;
+	t2 = (bmax[1] - r.o.y) * r.inv.y;
+	if (t1 > t2) { const float s = t1; t1 = t2; t2 = s; }
+	t2 *= widen;
+	tmin = fmax_(tmin, fmin_(t1, t2));
+	tmax = fmin_(tmax, fmax_(t1, t2));
+
+	t1 = (bmin[2] - r.o.z) * r.inv.z;
+	t2 = (bmax[2] - r.o.z) * r.inv.z;
+	if (t1 > t2) { const float s = t1; t1 = t2; t2 = s; }
+	t2 *= widen;
+	tmin = fmax_(tmin, fmin_(t1, t2));
+	tmax = fmin_(tmax, fmax_(t1, t2));
+
+	tmin_out = tmin;
+	return tmax > fmax_(tmin, 0.0f);
+}
+
+// Sphere::get_int up to the choice of t  sphere.rs:34-77
+__device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray &r, float &t)
+{
+	const V3 deltap = center - r.o;
+	const float ddp = dot(r.d, deltap);
+	const float deltapdot = dot(deltap, deltap);
+	const V3 remedy_term = deltap - ddp * r.d;
+	const float discriminant = radius * radius - dot(remedy_term, remedy_term);
+	if (!(discriminant > 0.0f))
+		return false;
+	const float sqrt_val = sqrtf(discriminant);
+	const float q = ddp > 0.0f ? ddp + sqrt_val : ddp - sqrt_val;
+	float t0 = q;
+	float t1 = (deltapdot - radius * radius) / q;
+	if (t1 < t0) { const float s = t0; t0 = t1; t1 = s; }
+	if (t0 > 0.0f) {
+		t = t0;
+		return true;
+	}
+	if (t1 <= 0.0f)
+		return false;
+	t = t1;
+	return true;
+}
+
+// triangle_intersection up to the barycentrics and t  triangle.rs:105-177
+__device__ __forceinline__ bool triangle_t(V3 P0, V3 P1, V3 P2, const Ray &r, float &t, float &b0, float &b1, float &b2)
+{
+	V3 p0t = P0 - r.o;
+	V3 p1t = P1 - r.o;
+	V3 p2t = P2 - r.o;
+	if (ray_swaps_xz(r)) {
+		float s;
+		s = p0t.x; p0t.x = p0t.z; p0t.z = s;
+		s = p1t.x; p1t.x = p1t.z; p1t.z = s;
+		s = p2t.x; p2t.x = p2t.z; p2t.z = s;
+	}
+	p0t.x += r.shear.x * p0t.z;
+	p0t.y += r.shear.y * p0t.z;
+	p1t.x += r.shear.x * p1t.z;
+	p1t.y += r.shear.y * p1t.z;
+	p2t.x += r.shear.x * p2t.z;
+	p2t.y += r.shear.y * p2t.z;
+
+	float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+	float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+	float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+	if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) { // f64 recompute  triangle.rs:128-132
+		e0 = (float)((double)p1t.x * (double)p2t.y - (double)p1t.y * (double)p2t.x);
+		e1 = (float)((double)p2t.x * (double)p0t.y - (double)p2t.y * (double)p0t.x);
+		e2 = (float)((double)p0t.x * (double)p1t.y - (double)p0t.y * (double)p1t.x);
+	}
+	if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f))
+		return false;
+	const float det = e0 + e1 + e2;
+	if (det == 0.0f)
+		return false;
+
+	p0t = p0t * r.shear.z;
+	p1t = p1t * r.shear.z;
+	p2t = p2t * r.shear.z;
+
+	const float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+	if ((det < 0.0f && t_scaled >= 0.0f) || (det > 0.0f && t_scaled <= 0.0f))
+		return false;
+
+	const float inv_det = 1.0f / det;
+	b0 = e0 * inv_det;
+	b1 = e1 * inv_det;
+	b2 = e2 * inv_det;
+	t = inv_det * t_scaled;
+
+	const float max_z_t = component_max(v3(fabsf(p0t.z), fabsf(p1t.z), fabsf(p2t.z)));
+	const float delta_z = gamma_n(3) * max_z_t;
+	const float max_x_t = component_max(v3(fabsf(p0t.x), fabsf(p1t.x), fabsf(p2t.x)));
+	const float max_y_t = component_max(v3(fabsf(p0t.y), fabsf(p1t.y), fabsf(p2t.y)));
+	const float delta_x = gamma_n(5) * (max_x_t + max_z_t);
+	const float delta_y = gamma_n(5) * (max_y_t + max_z_t);
+	const float delta_e = 2.0f * (gamma_n(2) * max_x_t * max_y_t + delta_y * max_x_t + delta_x * max_y_t);
+	const float max_e = component_max(v3(fabsf(e0), fabsf(e1), fabsf(e2)));
+	const float delta_t = 3.0f * (gamma_n(3) * max_e * max_z_t + delta_e * max_z_t + delta_z * max_e) * fabsf(inv_det);
+	if (t < delta_t)
+		return false;
+	return true;
+}
+
+// ---- primitive records ----
+struct PrimGeom {
+	uint32_t type, material;
+	V3 p0, p1, p2; // sphere: p0 = centre, p1.x = radius
+};
+__device__ __forceinline__ PrimGeom load_prim(const DevScene &S, uint32_t slot)
+{
+	const float4 *q = reinterpret_cast<const float4 *>(&S.prims[slot]);
+	const float4 a = q[0];
+	const float4 b = q[1];
+	PrimGeom g;
+	const uint32_t meta = __float_as_uint(a.w);
+	g.type = meta & 3u;
+	g.material = meta >> 2;
+	g.p0 = v3(a.x, a.y, a.z);
+	g.p1 = v3(b.x, b.y, b.z);
+	if (g.type != kPrimSphere) {
+		const float4 c = q[2];
+		g.p2 = v3(c.x, c.y, c.z);
+	} else {
+		g.p2 = v3(0.0f, 0.0f, 0.0f);
+	}
+	return g;
+}
+// Primitive::get_int reduced to (hit?, t)
+__device__ __forceinline__ bool prim_t(const PrimGeom &g, const Ray &r, float &t)
+{
+	if (g.type == kPrimSphere)
+		return sphere_t(g.p0, g.p1.x, r, t);
+	float b0, b1, b2;
+	return triangle_t(g.p0, g.p1, g.p2, r, t, b0, b1, b2);
+}
+
+// ---- Hit  rt_core/src/primitive.rs:3-10 ----
+struct Hit {
+	float t;
+	V3 point, error, normal;
+	float uvx, uvy;
+	bool has_uv, out;
+};
+
+// utility::check_side  utility/mod.rs:6-13
+__device__ __forceinline__ bool check_side(V3 &normal, V3 ray_direction)
+{
+	if (dot(normal, ray_direction) > 0.0f) {
+		normal = -normal;
+		return false;
+	}
+	return true;
+}
+
+// the rest of Sphere::get_int (sphere.rs:79-101) / triangle_intersection (triangle.rs:179-215)
+// for the primitive that won the traversal; recomputes t with the same code, so the value is the
+// one the traversal compared.
+__device__ __forceinline__ void make_hit(const DevScene &S, uint32_t slot, const Ray &r, Hit &h, uint32_t &material)
+{
+	const PrimGeom g = load_prim(S, slot);
+	material = g.material;
+	if (g.type == kPrimSphere) {
+		float t = 0.0f;
+		(void)sphere_t(g.p0, g.p1.x, r, t);
+		const V3 point = r.o + r.d * t;
+		V3 normal = (point - g.p0) / g.p1.x;
+		bool out = true;
+		if (dot(normal, r.d) > 0.0f) {
+			out = false;
+			normal = -normal;
+		}
+		h.t = t;
+		h.point = point;
+		h.error = kEpsilon * v3s(1.0f);
+		h.normal = normal;
+		h.uvx = h.uvy = 0.0f;
+		h.has_uv = false; // no material overrides Scatter::requires_uv (rt_core/src/material.rs:8-10)
+		h.out = out;
+		return;
+	}
+	float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+	(void)triangle_t(g.p0, g.p1, g.p2, r, t, b0, b1, b2);
+	const float4 *q = reinterpret_cast<const float4 *>(&S.shade[slot]);
+	const float4 n0 = q[0], n1 = q[1], n2 = q[2];
+	V3 normal = b0 * v3(n0.x, n0.y, n0.z) + b1 * v3(n1.x, n1.y, n1.z) + b2 * v3(n2.x, n2.y, n2.z);
+	const bool out = check_side(normal, r.d);
+	const float x_abs_sum = fabsf(b0 * g.p0.x) + fabsf(b1 * g.p1.x) + fabsf(b2 * g.p2.x);
+	const float y_abs_sum = fabsf(b0 * g.p0.y) + fabsf(b1 * g.p1.y) + fabsf(b2 * g.p2.y);
+	const float z_abs_sum = fabsf(b0 * g.p0.z) + fabsf(b1 * g.p1.z) + fabsf(b2 * g.p2.z);
+	h.t = t;
+	h.point = b0 * g.p0 + b1 * g.p1 + b2 * g.p2;
+	h.error = gamma_n(7) * v3(x_abs_sum, y_abs_sum, z_abs_sum) + gamma_n(6) * v3(b2 * g.p2.x, b2 * g.p2.y, b2 * g.p2.z);
+	h.normal = normal;
+	h.uvx = b0 * 0.0f + b1 * 1.0f + b2 * 1.0f; // b0*(0,0) + b1*(1,0) + b2*(1,1)
+	h.uvy = b0 * 0.0f + b1 * 0.0f + b2 * 1.0f;
+	h.has_uv = true;
+	h.out = out;
+}
+
+// Sky::get_si  sky.rs:79-92
+__device__ __forceinline__ void make_sky_hit(const DevScene &S, Hit &h, uint32_t &material)
+{
+	h.t = 0.0f;
+	h.point = h.error = h.normal = v3s(0.0f);
+	h.uvx = h.uvy = 0.0f;
+	h.has_uv = false;
+	h.out = false;
+	material = S.sky.material;
+}
+
+// ---- traversal ----
+// Per-lane stack in LDS: entry e of lane l lives at stack[e * 64 + l]; `stk` already points at
+// the lane's column, so consecutive lanes hit consecutive banks (conflict-free ds_read/ds_write_b32).
+constexpr int kStackStride = 64;
+// Slack used by the pruned walk: a child whose entry distance exceeds the current best t by more
+// than this cannot contain a primitive that beats or ties it (the slab test and the intersectors
+// agree to a few ulp; 3e-5 relative is ~250 ulp).  The exhaustive walk (prune = false) needs none.
+constexpr float kPruneSlack = 3.0e-5f;
+
+struct NodeView {
+	float c0min[3], c0max[3], c1min[3], c1max[3];
+	int32_t c0, c1;
+	uint32_t n0, n1;
+};
+__device__ __forceinline__ NodeView load_node(const DevScene &S, uint32_t node)
+{
+	const float4 *q = reinterpret_cast<const float4 *>(&S.nodes[node]);
+	const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	NodeView n;
+	n.c0min[0] = q0.x; n.c0min[1] = q0.y; n.c0min[2] = q0.z;
+	n.c0max[0] = q0.w; n.c0max[1] = q1.x; n.c0max[2] = q1.y;
+	n.c1min[0] = q1.z; n.c1min[1] = q1.w; n.c1min[2] = q2.x;
+	n.c1max[0] = q2.y; n.c1max[1] = q2.z; n.c1max[2] = q2.w;
+	n.c0 = (int32_t)__float_as_uint(q3.x);
+	n.c1 = (int32_t)__float_as_uint(q3.y);
+	n.n0 = __float_as_uint(q3.z);
+	n.n1 = __float_as_uint(q3.w);
+	return n;
+}
+__device__ __forceinline__ float box_extent_l1(const float mn[3], const float mx[3])
+{
+	return (mx[0] - mn[0]) + (mx[1] - mn[1]) + (mx[2] - mn[2]);
+}
+
+// Bvh::check_hit's selection rule over a leaf  mod.rs:270-293
+__device__ __forceinline__ void closest_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float &best_t,
+                                             uint32_t &best_prim)
+{
+	for (uint32_t slot = first; slot < first + count; ++slot) {
+		const PrimGeom g = load_prim(S, slot);
+		float t;
+		if (prim_t(g, r, t) && t > 0.0f) {
+			bool take;
+			if (best_prim == kNoPrim)
+				take = true;
+			else if (t < best_t)
+				take = true;
+			else if (t == best_t)
+				take = S.prim_rank[slot] < S.prim_rank[best_prim]; // reference order: first in BFS-leaf order wins
+			else
+				take = false;
+			if (take) {
+				best_t = t;
+				best_prim = slot;
+			}
+		}
+	}
+}
+
+template <bool PRUNE>
+__device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
+{
+	best_t = 0.0f;
+	best_prim = kNoPrim;
+	float tm;
+	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
+		return;
+	if (S.root_is_leaf) {
+		closest_leaf(S, r, 0, S.n_prims, best_t, best_prim);
+		return;
+	}
+	int sp = 0;
+	uint32_t node = 0;
+	for (;;) {
+		const NodeView n = load_node(S, node);
+		float t0, t1;
+		bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		if (PRUNE) {
+			if (h0 && h1 && t1 < t0 && n.c0 < 0 && n.c1 < 0) {
+				// two leaves: test the nearer first so the farther may be pruned
+				if (!(best_prim != kNoPrim && t1 - kPruneSlack * (fabsf(t1) + fabsf(best_t) + box_extent_l1(n.c1min, n.c1max)) > best_t))
+					closest_leaf(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
+				h1 = false;
+			}
+			if (h0 && best_prim != kNoPrim &&
+			    t0 - kPruneSlack * (fabsf(t0) + fabsf(best_t) + box_extent_l1(n.c0min, n.c0max)) > best_t)
+				h0 = false;
+		}
+		if (h0 && n.c0 < 0) {
+			closest_leaf(S, r, (uint32_t)~n.c0, n.n0, best_t, best_prim);
+			h0 = false;
+		}
+		if (PRUNE) {
+			if (h1 && best_prim != kNoPrim &&
+			    t1 - kPruneSlack * (fabsf(t1) + fabsf(best_t) + box_extent_l1(n.c1min, n.c1max)) > best_t)
+				h1 = false;
+		}
+		if (h1 && n.c1 < 0) {
+			closest_leaf(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
+			h1 = false;
+		}
+		if (h0 && h1) {
+			uint32_t near = (uint32_t)n.c0, far = (uint32_t)n.c1;
+			if (PRUNE && t1 < t0) {
+				near = (uint32_t)n.c1;
+				far = (uint32_t)n.c0;
+			}
+			stk[sp * kStackStride] = far;
+			++sp;
+			node = near;
+		} else if (h0) {
+			node = (uint32_t)n.c0;
+		} else if (h1) {
+			node = (uint32_t)n.c1;
+		} else {
+			if (sp == 0)
+				break;
+			--sp;
+			node = stk[sp * kStackStride];
+		}
+	}
+}
+
+// "is anything in the way": the occlusion rule shared by the sky shadow ray (Bvh::check_hit
+// returning an index != usize::MAX, mis.rs:104-115) and Bvh::check_hit_index (mod.rs:244-261):
+// some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
+// limit" (any t > 0 occludes).
+__device__ __forceinline__ bool any_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float t_limit, uint32_t skip)
+{
+	for (uint32_t slot = first; slot < first + count; ++slot) {
+		if (slot == skip)
+			continue;
+		const PrimGeom g = load_prim(S, slot);
+		float t;
+		if (prim_t(g, r, t) && t > 0.0f && !(t >= t_limit))
+			return true;
+	}
+	return false;
+}
+
+template <bool PRUNE>
+__device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
+{
+	float tm;
+	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
+		return false;
+	if (S.root_is_leaf)
+		return any_leaf(S, r, 0, S.n_prims, t_limit, skip);
+	int sp = 0;
+	uint32_t node = 0;
+	for (;;) {
+		const NodeView n = load_node(S, node);
+		float t0, t1;
+		bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		if (PRUNE) { // t_limit NaN: comparisons are false, nothing is pruned
+			if (h0 && t0 - kPruneSlack * (fabsf(t0) + fabsf(t_limit) + box_extent_l1(n.c0min, n.c0max)) > t_limit)
+				h0 = false;
+			if (h1 && t1 - kPruneSlack * (fabsf(t1) + fabsf(t_limit) + box_extent_l1(n.c1min, n.c1max)) > t_limit)
+				h1 = false;
+		}
+		if (h0 && n.c0 < 0) {
+			if (any_leaf(S, r, (uint32_t)~n.c0, n.n0, t_limit, skip))
+				return true;
+			h0 = false;
+		}
+		if (h1 && n.c1 < 0) {
+			if (any_leaf(S, r, (uint32_t)~n.c1, n.n1, t_limit, skip))
+				return true;
+			h1 = false;
+		}
+		if (h0 && h1) {
+			stk[sp * kStackStride] = (uint32_t)n.c1;
+			++sp;
+			node = (uint32_t)n.c0;
+		} else if (h0) {
+			node = (uint32_t)n.c0;
+		} else if (h1) {
+			node = (uint32_t)n.c1;
+		} else {
+			if (sp == 0)
+				return false;
+			--sp;
+			node = stk[sp * kStackStride];
+		}
+	}
+}
+
+} // namespace rt

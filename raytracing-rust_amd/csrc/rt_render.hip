@@ -1,0 +1,551 @@
+// rt_render.hip -- the gfx950 render kernels: sampler + integrators of the reference as ONE
+// persistent launch per image.
+//
+// Reference control flow (CPU): RandomSampler::sample_image runs spp serial passes, each a rayon
+// par_chunks_mut over 10 000-pixel chunks with a barrier, each pixel calling
+// Mis/NaiveIntegrator::get_colour; the caller folds every pass into a running mean
+// (samplers/random_sampler.rs:10-99, integrators/mod.rs:22-78, integrators/mis.rs:7-157,
+// src/main.rs:175-191).
+//
+// MI355X design: there are no passes.  A lane OWNS a pixel for all of its samples: it draws the
+// camera ray, walks the path, folds the sample into the pixel's running mean in registers
+// (`mean += (sample - mean) / i`, the reference's own update, in sample order -- so the mean is
+// bit-identical to the reference's accumulation order), and writes the pixel once.  Paths last
+// 1..49 bounces, so lanes of a wavefront finish samples at different times; a finished lane
+// immediately regenerates the next sample (or pulls the next pixel from a global queue with one
+// wave-aggregated atomic: __ballot + popcount + one atomicAdd per wave) instead of idling until
+// the longest path of the wave ends.  Every loop iteration is one bounce for all 64 lanes:
+//   [A] closest-hit walk of the lane's current ray (camera ray or bounce ray)
+//   [B] shade: emission, MIS weight, Russian roulette, or sample finished
+//   [C] light sample (sky table in LDS / light primitive) + any-hit shadow walk
+//   [D] BSDF sample -> next bounce ray
+// Scene data is read-only and shared: BVH / primitives through L1/L2 from HBM, the sky's CDF rows
+// staged once per workgroup into LDS next to the per-lane traversal stacks.  HBM write traffic is
+// 12 bytes per pixel for the whole render.  No MFMA: nothing here is a dense contraction.
+#include "rt_shade.h"
+
+namespace rt {
+
+enum : int { ST_NEED_PIXEL = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+
+__device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt_core/src/lib.rs:36-40
+{
+	const float a_sq = pdf_a * pdf_a;
+	return a_sq / (a_sq + pdf_b * pdf_b);
+}
+
+// work item -> pixel.  Work items enumerate this shard's tiles (tile t belongs to shard
+// t % shard_count) row-major inside each tile, so the 64 lanes of a wave start on one compact
+// tile_w x tile_h block of the image (coherent primary rays).
+__device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t w, uint32_t &x, uint32_t &y)
+{
+	const uint32_t tile_pixels = P.tile_w * P.tile_h;
+	const uint32_t k = w / tile_pixels;
+	const uint32_t in = w - k * tile_pixels;
+	const uint32_t tile = P.shard_index + k * P.shard_count;
+	const uint32_t ty = tile / P.tiles_x;
+	const uint32_t tx = tile - ty * P.tiles_x;
+	x = tx * P.tile_w + in % P.tile_w;
+	y = ty * P.tile_h + in / P.tile_w;
+	return x < P.width && y < P.height;
+}
+
+__device__ __forceinline__ bool lights_contain(const DevScene &S, uint32_t prim) // bvh.get_samplable().contains(&index)  mis.rs:58
+{
+	for (uint32_t i = 0; i < S.n_lights; ++i)
+		if (S.lights[i] == prim)
+			return true;
+	return false;
+}
+
+template <int METHOD, bool PRUNE, bool SKY_LDS>
+__global__ __launch_bounds__(256) void render_kernel(const DevScene S, const DevCamera cam, const DevRenderParams P,
+                                                     float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
+                                                     uint32_t *__restrict__ work_counter)
+{
+	extern __shared__ __align__(16) uint32_t lds[];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+
+	// ---- stage the sky CDF rows + marginal CDF into LDS ----
+	SkyTables T;
+	uint32_t sky_words = 0;
+	if (SKY_LDS) {
+		const uint32_t n_rows = S.sky.res_y * (S.sky.res_x + 1u);
+		const uint32_t n_all = n_rows + S.sky.res_y + 1u;
+		float *lds_sky = reinterpret_cast<float *>(lds);
+		for (uint32_t i = threadIdx.x; i < n_all; i += blockDim.x)
+			lds_sky[i] = S.sky.row_cdf[i]; // marginal follows the rows in the same allocation
+		__syncthreads();
+		T.row_cdf = lds_sky;
+		T.marginal_cdf = lds_sky + n_rows;
+		sky_words = (n_all + 3u) & ~3u;
+	} else {
+		T.row_cdf = S.sky.row_cdf;
+		T.marginal_cdf = S.sky.marginal_cdf;
+	}
+	uint32_t *stk = lds + sky_words + wave * (S.stack_depth * kStackStride) + lane;
+
+	const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
+	const uint64_t sample_begin = ((uint64_t)P.sample_begin_hi << 32) | P.sample_begin_lo;
+	const V3 cam_o = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+	const V3 cam_ll = v3(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
+	const V3 cam_h = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+	const V3 cam_v = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+	const bool sky_samplable = sky_can_sample(S);
+
+	// ---- per-lane path state (registers) ----
+	int st = ST_NEED_PIXEL;
+	rt_rng rng = {1u, 2u, 3u, 4u};
+	Ray ray;
+	ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
+	V3 thr = v3s(1.0f), outp = v3s(0.0f), mean = v3s(0.0f), wo = v3s(0.0f);
+	Hit hit;
+	hit.t = 0.0f;
+	hit.point = hit.error = hit.normal = v3s(0.0f);
+	hit.uvx = hit.uvy = 0.0f;
+	hit.has_uv = hit.out = false;
+	uint32_t mat = 0;
+	uint32_t depth = 0, sample_local = 0, out_index = 0, pixel_index = 0, px = 0, py = 0;
+	uint32_t ray_count = 0;
+	unsigned long long rays_total = 0;
+	bool primary = true;
+
+	for (;;) {
+		// ---- work acquisition: one atomic per wave for all lanes that ran out of samples ----
+		{
+			const unsigned long long need = __ballot(st == ST_NEED_PIXEL);
+			if (need != 0ull) {
+				const uint32_t n = (uint32_t)__popcll(need);
+				const int leader = __ffsll((long long)need) - 1;
+				uint32_t base = 0;
+				if ((int)lane == leader)
+					base = atomicAdd(work_counter, n);
+				base = __shfl(base, leader);
+				if (st == ST_NEED_PIXEL) {
+					const uint32_t w = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+					if (w >= P.n_work) {
+						st = ST_DONE;
+					} else if (work_to_pixel(P, w, px, py)) {
+						pixel_index = py * P.width + px;
+						out_index = P.shard_layout ? w : pixel_index;
+						sample_local = 0;
+						mean = v3s(0.0f);
+						st = ST_NEW_SAMPLE;
+					} // else: padding of an edge tile; ask again next iteration
+				}
+			}
+		}
+		if (__ballot(st != ST_DONE) == 0ull)
+			break;
+
+		// ---- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61 ----
+		if (st == ST_NEW_SAMPLE) {
+			rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
+			const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
+			const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
+			// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
+			ray = ray_new(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
+			(void)rt_rng_f32(&rng);
+			thr = v3s(1.0f);
+			outp = v3s(0.0f);
+			depth = 0;
+			ray_count = 0;
+			primary = true;
+			st = ST_TRACE;
+		}
+		const bool act = (st == ST_TRACE);
+
+		// ---- [A] Bvh::check_hit for the lane's current ray ----
+		float best_t = 0.0f;
+		uint32_t prim = kNoPrim;
+		if (act)
+			trace_closest<PRUNE>(S, ray, stk, best_t, prim);
+
+		bool finish = false;
+		bool filter = true; // apply the NaN / non-finite filter (integrators/mod.rs:74-76, mis.rs:88-90)
+
+		if (act) {
+			Hit nh;
+			uint32_t nmat;
+			if (prim != kNoPrim)
+				make_hit(S, prim, ray, nh, nmat);
+			else
+				make_sky_hit(S, nh, nmat);
+
+			if (METHOD == 0) {
+				// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
+				ray_count += 1;
+				const V3 wo_n = ray.d;
+				const V3 emission = mat_get_emission(S, nmat, nh, wo_n);
+				const bool exit = mat_scatter_ray(S, nmat, ray, nh, rng);
+				if (depth == 0) {
+					outp = outp + emission;
+					if (exit)
+						finish = true;
+				}
+				if (!finish && exit) {
+					outp = outp + thr * emission;
+					finish = true;
+				}
+				if (!finish) {
+					if (!mat_is_delta(S, nmat))
+						thr = thr * mat_eval_over_pdf(S, nmat, nh, wo_n, ray.d);
+					else
+						thr = thr * mat_eval(S, nmat, nh, wo_n, ray.d);
+					if (depth > P.rr_threshold) {
+						const float p = component_max(thr);
+						if (rt_rng_f32(&rng) > p)
+							finish = true;
+						else
+							thr = thr / p;
+					}
+					if (!finish) {
+						depth += 1;
+						if (!(depth < P.max_depth))
+							finish = true;
+					}
+				}
+			} else if (primary) {
+				// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
+				wo = ray.d;
+				hit = nh;
+				mat = nmat;
+				const V3 emission = mat_get_emission(S, mat, hit, wo);
+				Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
+				const bool exit = mat_scatter_ray(S, mat, clone, hit, rng);
+				outp = outp + emission;
+				if (exit) {
+					finish = true;
+					filter = false; // mis.rs:29-31 returns before the filter
+				} else {
+					depth = 1;
+					primary = false;
+					if (!(depth < P.max_depth))
+						finish = true;
+				}
+			} else {
+				// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
+				const V3 m_wi = ray.d;
+				const float m_pdf = mat_scattering_pdf(S, mat, hit, wo, m_wi);
+				const V3 le = mat_get_emission(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
+				thr = thr * mat_eval_over_pdf(S, mat, hit, wo, m_wi);
+				if (!is_zero(le)) {
+					const bool on_light = (prim != kNoPrim) && lights_contain(S, prim) && !mat_is_delta(S, mat);
+					if (on_light || (prim == kNoPrim && sky_samplable)) {
+						// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
+						const float divisor = (float)(sky_samplable ? S.n_lights + 1u : S.n_lights);
+						float l_pdf;
+						if (prim == kNoPrim) {
+							l_pdf = sky_pdf(S, T, m_wi) / divisor;
+						} else {
+							const PrimGeom g = load_prim(S, prim);
+							l_pdf = prim_scattering_pdf(g, hit.point, m_wi, nh) / divisor;
+						}
+						const float mis_weight = power_heuristic(m_pdf, l_pdf);
+						outp = outp + thr * le * mis_weight;
+					} else {
+						outp = outp + thr * le;
+					}
+				}
+				if (mat_is_light(S, nmat)) {
+					finish = true;
+				} else {
+					if (depth > P.rr_threshold) {
+						const float p = component_max(thr);
+						if (rt_rng_f32(&rng) > p)
+							finish = true;
+						else
+							thr = thr / p;
+					}
+					if (!finish) {
+						wo = m_wi;
+						hit = nh;
+						mat = nmat;
+						depth += 1;
+						if (!(depth < P.max_depth))
+							finish = true;
+					}
+				}
+			}
+		}
+
+		if (METHOD == 1) {
+			// ---- [C] sample_lights  mis.rs:95-157, for lanes whose path continues ----
+			const bool cont = act && !finish;
+			bool have_shadow = false, shadow_is_sky = false;
+			Ray sray;
+			sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
+			V3 l_wi = v3s(0.0f);
+			float pdf_multiplier = 1.0f, t_limit = 0.0f;
+			uint32_t light_prim = kNoPrim;
+			if (cont) {
+				ray_count += 1; // mis.rs:38
+				const uint32_t samplable_len = S.n_lights;
+				bool pick_sky = false, pick_light = false;
+				uint32_t light_slot = 0;
+				if (samplable_len == 0u) {
+					pick_sky = sky_samplable; // (0,true) => sample_sky(1.0); (0,false) => None
+				} else if (!sky_samplable) {
+					pdf_multiplier = 1.0f / (float)samplable_len;
+					light_slot = rt_rng_below(&rng, samplable_len); // gen_range(0..len)
+					pick_light = true;
+				} else {
+					pdf_multiplier = 1.0f / (float)(samplable_len + 1u);
+					light_slot = rt_rng_below(&rng, samplable_len + 1u); // gen_range(0..=len)
+					if (light_slot == samplable_len)
+						pick_sky = true;
+					else
+						pick_light = true;
+				}
+				const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
+				if (pick_sky) {
+					l_wi = sky_sample(S, T, rng);
+					sray = ray_new(shadow_origin, l_wi);
+					t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
+					have_shadow = true;
+					shadow_is_sky = true;
+				} else if (pick_light) {
+					light_prim = S.lights[light_slot];
+					const PrimGeom g = load_prim(S, light_prim);
+					l_wi = prim_sample_visible_from_point(g, hit.point, rng);
+					sray = ray_new(shadow_origin, l_wi);
+					float lt;
+					if (prim_t(g, sray, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
+						t_limit = lt;
+						have_shadow = true;
+					}
+				}
+			}
+			bool occluded = false;
+			if (have_shadow)
+				occluded = trace_any<PRUNE>(S, sray, stk, t_limit, light_prim);
+			if (cont) {
+				if (have_shadow && !occluded) {
+					bool valid = false;
+					V3 le = v3s(0.0f);
+					float l_pdf = 0.0f;
+					if (shadow_is_sky) { // sample_sky  mis.rs:104-115
+						le = mat_get_emission(S, S.sky.material, hit, l_wi);
+						l_pdf = sky_pdf(S, T, l_wi) * pdf_multiplier;
+						valid = true;
+					} else { // sample_light  mis.rs:117-133
+						Hit lh;
+						uint32_t lm;
+						make_hit(S, light_prim, sray, lh, lm);
+						const PrimGeom g = load_prim(S, light_prim);
+						const float p = prim_scattering_pdf(g, hit.point, l_wi, lh);
+						if (p > 0.0f) {
+							le = mat_get_emission(S, lm, lh, l_wi);
+							l_pdf = p * pdf_multiplier;
+							valid = true;
+						}
+					}
+					if (valid) { // mis.rs:39-43
+						const float m_pdf = mat_scattering_pdf(S, mat, hit, wo, l_wi);
+						const float mis_weight = power_heuristic(l_pdf, m_pdf);
+						outp = outp + thr * mat_eval(S, mat, hit, wo, l_wi) * mis_weight * le / l_pdf;
+					}
+				}
+				// ---- [D] material sampling  mis.rs:46-49 ----
+				if (mat_scatter_ray(S, mat, ray, hit, rng))
+					finish = true;
+			}
+		}
+
+		// ---- sample finished: filter, fold into the running mean, next sample or next pixel ----
+		if (act && finish) {
+			V3 c = outp;
+			if (filter && (contains_nan(c) || !is_finite_any(c)))
+				c = v3s(0.0f);
+			const float i_f = (float)(sample_local + 1u);
+			mean.x += (c.x - mean.x) / i_f; // src/main.rs:179-185
+			mean.y += (c.y - mean.y) / i_f;
+			mean.z += (c.z - mean.z) / i_f;
+			rays_total += ray_count;
+			sample_local += 1;
+			if (sample_local == P.spp) {
+				out[3u * (size_t)out_index + 0u] = mean.x;
+				out[3u * (size_t)out_index + 1u] = mean.y;
+				out[3u * (size_t)out_index + 2u] = mean.z;
+				st = ST_NEED_PIXEL;
+			} else {
+				st = ST_NEW_SAMPLE;
+			}
+		}
+	}
+
+	// ---- SamplerProgress.rays_shot: wave reduction, one atomic per wave ----
+	if (rays_shot != nullptr) {
+		for (int off = 32; off > 0; off >>= 1)
+			rays_total += __shfl_down(rays_total, off);
+		if (lane == 0u)
+			atomicAdd(rays_shot, rays_total);
+	}
+}
+
+// ---- batch hit queries (AccelerationStructure::check_hit / check_hit_index) ----
+struct DevRayDesc {
+	float origin[3], direction[3];
+};
+struct DevHitRecord {
+	float t, point[3], error[3], normal[3], uv[2];
+	int32_t has_uv, out;
+	uint32_t material, found;
+	unsigned long long index;
+};
+static_assert(sizeof(DevHitRecord) == 72, "must match rt_hit_record");
+
+__device__ __forceinline__ void store_record(DevHitRecord &o, const Hit &h, uint32_t material, unsigned long long index, bool found)
+{
+	o.t = h.t;
+	o.point[0] = h.point.x; o.point[1] = h.point.y; o.point[2] = h.point.z;
+	o.error[0] = h.error.x; o.error[1] = h.error.y; o.error[2] = h.error.z;
+	o.normal[0] = h.normal.x; o.normal[1] = h.normal.y; o.normal[2] = h.normal.z;
+	o.uv[0] = h.uvx; o.uv[1] = h.uvy;
+	o.has_uv = h.has_uv ? 1 : 0;
+	o.out = h.out ? 1 : 0;
+	o.material = material;
+	o.found = found ? 1u : 0u;
+	o.index = index;
+}
+
+template <bool PRUNE>
+__global__ __launch_bounds__(256) void check_hit_kernel(const DevScene S, const DevRayDesc *__restrict__ rays, uint64_t n,
+                                                        DevHitRecord *__restrict__ outr)
+{
+	extern __shared__ __align__(16) uint32_t lds[];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const Ray r = ray_new(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
+	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
+	float t;
+	uint32_t prim;
+	trace_closest<PRUNE>(S, r, stk, t, prim);
+	Hit h;
+	uint32_t m;
+	if (prim != kNoPrim) {
+		make_hit(S, prim, r, h, m);
+		store_record(outr[i], h, m, prim, true);
+	} else {
+		make_sky_hit(S, h, m);
+		store_record(outr[i], h, m, 0xFFFFFFFFFFFFFFFFull, true);
+	}
+}
+
+template <bool PRUNE>
+__global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, const DevRayDesc *__restrict__ rays,
+                                                              const unsigned long long *__restrict__ object_index, uint64_t n,
+                                                              DevHitRecord *__restrict__ outr)
+{
+	extern __shared__ __align__(16) uint32_t lds[];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const Ray r = ray_new(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
+	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
+	const uint32_t index = (uint32_t)object_index[i];
+	const PrimGeom g = load_prim(S, index);
+	Hit h;
+	h.t = 0.0f;
+	h.point = h.error = h.normal = v3s(0.0f);
+	h.uvx = h.uvy = 0.0f;
+	h.has_uv = h.out = false;
+	uint32_t m = 0;
+	bool found = false;
+	float lt;
+	if (prim_t(g, r, lt) && lt > 0.0f) {
+		if (!trace_any<PRUNE>(S, r, stk, lt, index)) {
+			make_hit(S, index, r, h, m);
+			found = true;
+		}
+	}
+	store_record(outr[i], h, m, object_index[i], found);
+}
+
+// ---- launchers (called from rt_api.cpp) ----
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_block)
+{
+	size_t words = 0;
+	if (sky_lds) {
+		const uint32_t n_all = S.sky.res_y * (S.sky.res_x + 1u) + S.sky.res_y + 1u;
+		words += (n_all + 3u) & ~3u;
+	}
+	words += (size_t)waves_per_block * S.stack_depth * kStackStride;
+	return words * sizeof(uint32_t);
+}
+
+typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams, float *, unsigned long long *, uint32_t *);
+
+static render_fn pick_render(int method, bool prune, bool sky_lds)
+{
+#define RT_PICK(M, P, L) \
+	if (method == M && prune == P && sky_lds == L) \
+		return render_kernel<M, P, L>;
+	RT_PICK(0, false, false)
+	RT_PICK(0, false, true)
+	RT_PICK(0, true, false)
+	RT_PICK(0, true, true)
+	RT_PICK(1, false, false)
+	RT_PICK(1, false, true)
+	RT_PICK(1, true, false)
+	RT_PICK(1, true, true)
+#undef RT_PICK
+	return nullptr;
+}
+
+hipError_t render_occupancy(int method, bool prune, bool sky_lds, size_t lds_bytes, int *blocks_per_cu)
+{
+	render_fn fn = pick_render(method, prune, sky_lds);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess)
+		return e;
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 256, lds_bytes);
+}
+
+hipError_t launch_render(int method, bool prune, bool sky_lds, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+                         const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
+                         unsigned long long *rays_shot, uint32_t *work_counter)
+{
+	render_fn fn = pick_render(method, prune, sky_lds);
+	if (!fn)
+		return hipErrorInvalidValue;
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(256), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
+	return hipGetLastError();
+}
+
+hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out)
+{
+	const size_t lds_bytes = (size_t)4 * S.stack_depth * kStackStride * sizeof(uint32_t);
+	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	if (prune)
+		hipLaunchKernelGGL(check_hit_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, S,
+		                   static_cast<const DevRayDesc *>(rays), n, static_cast<DevHitRecord *>(out));
+	else
+		hipLaunchKernelGGL(check_hit_kernel<false>, dim3(blocks), dim3(256), lds_bytes, stream, S,
+		                   static_cast<const DevRayDesc *>(rays), n, static_cast<DevHitRecord *>(out));
+	return hipGetLastError();
+}
+
+hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
+                                  uint64_t n, void *out)
+{
+	const size_t lds_bytes = (size_t)4 * S.stack_depth * kStackStride * sizeof(uint32_t);
+	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	if (prune)
+		hipLaunchKernelGGL(check_hit_index_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, S,
+		                   static_cast<const DevRayDesc *>(rays), static_cast<const unsigned long long *>(object_index), n,
+		                   static_cast<DevHitRecord *>(out));
+	else
+		hipLaunchKernelGGL(check_hit_index_kernel<false>, dim3(blocks), dim3(256), lds_bytes, stream, S,
+		                   static_cast<const DevRayDesc *>(rays), static_cast<const unsigned long long *>(object_index), n,
+		                   static_cast<DevHitRecord *>(out));
+	return hipGetLastError();
+}
+
+} // namespace rt

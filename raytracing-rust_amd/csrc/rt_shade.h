@@ -1,0 +1,499 @@
+// rt_shade.h -- the per-bounce shade/sample step on the device: textures, the importance-sampled
+// sky, the five materials and their BxDF math.
+//
+// Reference (paths under crates/implementations/src/): textures/mod.rs:9-291,
+// statistics/distributions.rs:51-72,100-110, sky.rs:43-92, materials/{emissive,lambertian,reflect,
+// refract,trowbridge_reitz}.rs, statistics/bxdfs/{lambertian,trowbridge_reitz,
+// trowbridge_reitz_vndf}.rs, utility/{mod,coord}.rs.  The enum dispatch the reference generates with
+// proc macros (proc/src/lib.rs) is a switch on the type tag here.
+#pragma once
+
+#include "rt_intersect.h"
+
+namespace rt {
+
+// ---- utility/mod.rs ----
+__device__ __forceinline__ float next_float(float f) // :51-65
+{
+	if (f == INFINITY)
+		return f;
+	if (f == 0.0f) // catches -0.0 too; the reference sets it to +0.0
+		f = 0.0f;
+	const uint32_t bits = __float_as_uint(f);
+	return __uint_as_float(f >= 0.0f ? bits + 1u : bits - 1u);
+}
+__device__ __forceinline__ float previous_float(float f) // :67-81
+{
+	if (f == -INFINITY)
+		return f;
+	if (f == 0.0f)
+		f = -0.0f;
+	const uint32_t bits = __float_as_uint(f);
+	return __uint_as_float(f <= 0.0f ? bits + 1u : bits - 1u);
+}
+__device__ __forceinline__ V3 offset_ray(V3 origin, V3 normal, V3 error, bool is_brdf) // :88-117
+{
+	const float offset_val = dot(vabs(normal), error);
+	V3 offset = offset_val * normal;
+	if (!is_brdf)
+		offset = -offset;
+	V3 o = origin + offset;
+	o.x = offset.x > 0.0f ? next_float(o.x) : previous_float(o.x);
+	o.y = offset.y > 0.0f ? next_float(o.y) : previous_float(o.y);
+	o.z = offset.z > 0.0f ? next_float(o.z) : previous_float(o.z);
+	return o;
+}
+__device__ __forceinline__ V3 random_unit_vector(rt_rng &rng) // :15-25
+{
+	float x = 1.0f, y = 1.0f, z = 1.0f;
+	while (x * x + y * y + z * z > 1.0f) {
+		x = rt_rng_range_f32(&rng, -1.0f, 1.0f);
+		y = rt_rng_range_f32(&rng, -1.0f, 1.0f);
+		z = rt_rng_range_f32(&rng, -1.0f, 1.0f);
+	}
+	return normalised(v3(x, y, z));
+}
+
+// ---- utility/coord.rs:9-31 ----
+struct Coord {
+	V3 x, y, z;
+};
+__device__ __forceinline__ Coord coord_from_z(V3 z)
+{
+	Coord c;
+	if (fabsf(z.x) > fabsf(z.y))
+		c.x = v3(-z.z, 0.0f, z.x) / sqrtf(z.x * z.x + z.z * z.z);
+	else
+		c.x = v3(0.0f, z.z, -z.y) / sqrtf(z.y * z.y + z.z * z.z);
+	c.y = cross(c.x, z);
+	c.z = z;
+	return c;
+}
+__device__ __forceinline__ Coord coord_inverse(const Coord &c)
+{
+	Coord r;
+	r.x = v3(c.x.x, c.y.x, c.z.x);
+	r.y = v3(c.x.y, c.y.y, c.z.y);
+	r.z = v3(c.x.z, c.y.z, c.z.z);
+	return r;
+}
+__device__ __forceinline__ V3 to_coord(const Coord &c, V3 v) { return v.x * c.x + v.y * c.y + v.z * c.z; }
+
+// Rust `as usize` / `as i32` on floats saturate and map NaN to 0
+__device__ __forceinline__ uint32_t f32_as_index(float f)
+{
+	if (!(f > 0.0f))
+		return 0u;
+	if (f >= 4294967040.0f)
+		return 0xFFFFFFFFu;
+	return (uint32_t)f;
+}
+__device__ __forceinline__ int32_t f32_as_i32(float f)
+{
+	if (f != f)
+		return 0;
+	if (f >= 2147483648.0f)
+		return 2147483647;
+	if (f <= -2147483648.0f)
+		return (-2147483647 - 1);
+	return (int32_t)f;
+}
+
+// ---- textures/mod.rs ----
+__device__ inline float perlin_noise(const DevTexture &t, V3 point) // :110-169
+{
+	const float u = point.x - floorf(point.x);
+	const float v = point.y - floorf(point.y);
+	const float w = point.z - floorf(point.z);
+	const int32_t i = f32_as_i32(floorf(point.x));
+	const int32_t j = f32_as_i32(floorf(point.y));
+	const int32_t k = f32_as_i32(floorf(point.z));
+	const float uu = u * u * (3.0f - 2.0f * u);
+	const float vv = v * v * (3.0f - 2.0f * v);
+	const float ww = w * w * (3.0f - 2.0f * w);
+	float value = 0.0f;
+	for (int index = 0; index < 8; ++index) {
+		const int ii = index / 4, jj = (index / 2) % 2, kk = index % 2;
+		const uint32_t a = t.perlin_perm[(uint32_t)(i + ii) & 255u] ^ t.perlin_perm[256 + ((uint32_t)(j + jj) & 255u)] ^
+		                   t.perlin_perm[512 + ((uint32_t)(k + kk) & 255u)];
+		const float *rv = t.perlin_vecs + 3 * (a & 255u);
+		const V3 c = v3(rv[0], rv[1], rv[2]);
+		const float fi = (float)ii, fj = (float)jj, fk = (float)kk;
+		const V3 weight = v3(u - fi, v - fj, w - fk);
+		value += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) *
+		         (fk * ww + (1.0f - fk) * (1.0f - ww)) * dot(c, weight);
+	}
+	return value;
+}
+
+__device__ __forceinline__ V3 texture_colour(const DevScene &S, uint32_t tex, V3 direction, V3 point)
+{
+	const DevTexture &t = S.textures[tex];
+	const int type = t.type;
+	if (type == 1) // SolidColour :193-200
+		return v3(t.c1[0], t.c1[1], t.c1[2]);
+	if (type == 3) { // Lerp :283-291
+		const float tt = direction.z * 0.5f + 0.5f;
+		return v3(t.c1[0], t.c1[1], t.c1[2]) * tt + v3(t.c2[0], t.c2[1], t.c2[2]) * (1.0f - tt);
+	}
+	if (type == 0) { // CheckeredTexture :61-73
+		const float sign = rt_sinf(10.0f * point.x) * rt_sinf(10.0f * point.y) * rt_sinf(10.0f * point.z);
+		return sign > 0.0f ? v3(t.c1[0], t.c1[1], t.c1[2]) : v3(t.c2[0], t.c2[1], t.c2[2]);
+	}
+	if (type == 2) { // ImageTexture :251-262
+		const float phi = rt_atan2f(direction.y, direction.x) + kPi;
+		const float theta = rt_acosf(direction.z);
+		const float uvx = phi / (2.0f * kPi);
+		const float uvy = theta / kPi;
+		const uint32_t x_pixel = f32_as_index((float)t.dim_x * uvx);
+		const uint32_t y_pixel = f32_as_index((float)t.dim_y * uvy);
+		uint64_t index = (uint64_t)y_pixel * (t.dim_x + 1u) + x_pixel;
+		const uint64_t n = (uint64_t)(t.dim_x + 1u) * (t.dim_y + 1u);
+		if (index >= n) // the reference would panic here
+			index = n - 1;
+		const float *px = t.image + 3 * index;
+		return v3(px[0], px[1], px[2]);
+	}
+	if (type == 4) // Perlin :171-179
+		return (0.5f * v3s(1.0f)) * (1.0f + perlin_noise(t, point));
+	return v3s(1.0f);
+}
+
+// ---- statistics/distributions.rs ----
+// Distribution1D::sample :51-72 over a cdf of n+1 entries
+__device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, rt_rng &rng)
+{
+	const float num = rt_rng_f32(&rng);
+	uint32_t first = 0;
+	uint32_t len = n + 1;
+	while (len > 0) {
+		const uint32_t half = len >> 1;
+		const uint32_t middle = first + half;
+		if (cdf[middle] <= num) {
+			first = middle + 1;
+			len -= half + 1;
+		} else {
+			len = half;
+		}
+	}
+	const uint32_t v = first - 1u; // cdf[0] = 0 <= num, so first >= 1
+	return v > n - 1u ? n - 1u : v;
+}
+
+struct SkyTables {
+	const float *row_cdf;      // [res_y][res_x + 1]
+	const float *marginal_cdf; // [res_y + 1]
+};
+
+__device__ __forceinline__ bool sky_can_sample(const DevScene &S) { return (S.sky.res_x | S.sky.res_y) != 0u; } // sky.rs:61-63
+
+// Sky::pdf  sky.rs:43-60 with Distribution2D::pdf distributions.rs:105-110
+__device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, V3 wi)
+{
+	const float sin_theta = sqrtf(1.0f - wi.z * wi.z);
+	if (sin_theta <= 0.0f)
+		return 0.0f;
+	const float theta = rt_acosf(wi.z);
+	float phi = rt_atan2f(wi.y, wi.x);
+	if (phi < 0.0f)
+		phi += 2.0f * kPi;
+	const float u = phi / (2.0f * kPi);
+	const float v = theta / kPi;
+	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
+	uint32_t ui = f32_as_index((float)rx * u);
+	uint32_t vi = f32_as_index((float)ry * v);
+	ui = ui > rx - 1u ? rx - 1u : ui;
+	vi = vi > ry - 1u ? ry - 1u : vi;
+	// pdf[i] = cdf[i+1] - cdf[i]: the subtraction Distribution1D::new performs (:32-38)
+	const float ypdf = T.marginal_cdf[vi + 1u] - T.marginal_cdf[vi];
+	const float *row = T.row_cdf + (size_t)vi * (rx + 1u);
+	const float xpdf = row[ui + 1u] - row[ui];
+	return (float)rx * (float)ry * (ypdf * xpdf) / (sin_theta * kTau * kPi);
+}
+
+// Sky::sample  sky.rs:64-78
+__device__ __forceinline__ V3 sky_sample(const DevScene &S, const SkyTables &T, rt_rng &rng)
+{
+	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
+	const uint32_t sv = dist1d_sample(T.marginal_cdf, ry, rng);
+	const uint32_t su = dist1d_sample(T.row_cdf + (size_t)sv * (rx + 1u), rx, rng);
+	const float u = next_float((float)su + rt_rng_f32(&rng)) / (float)rx;
+	const float v = next_float((float)sv + rt_rng_f32(&rng)) / (float)ry;
+	const float phi = u * 2.0f * kPi;
+	const float theta = v * kPi;
+	const float st = rt_sinf(theta), ct = rt_cosf(theta), sp = rt_sinf(phi), cp = rt_cosf(phi);
+	return v3(st * cp, st * sp, ct); // Vec3::from_spherical  vec.rs:155-163
+}
+
+// ---- statistics/bxdfs ----
+__device__ __forceinline__ V3 lambertian_sample(V3 normal, rt_rng &rng) // lambertian.rs:5-18
+{
+	const float cos_theta = sqrtf(1.0f - rt_rng_f32(&rng));
+	const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+	const float phi = 2.0f * kPi * rt_rng_f32(&rng);
+	const V3 local = v3(rt_cosf(phi) * sin_theta, rt_sinf(phi) * sin_theta, cos_theta);
+	const Coord c = coord_from_z(normal);
+	return to_coord(c, local);
+}
+__device__ __forceinline__ float tr_d(float alpha, float cos_theta) // trowbridge_reitz.rs:14-21
+{
+	if (cos_theta <= 0.0f)
+		return 0.0f;
+	const float a_sq = alpha * alpha;
+	const float tmp = cos_theta * cos_theta * (a_sq - 1.0f) + 1.0f;
+	return a_sq / (kPi * tmp * tmp);
+}
+__device__ __forceinline__ float tr_g2(float alpha, V3 normal, V3 h, V3 incoming, V3 outgoing) // :61-78
+{
+	if (dot(incoming, h) / dot(incoming, normal) <= 0.0f || dot(outgoing, h) / dot(outgoing, normal) <= 0.0f)
+		return 0.0f;
+	const float alpha_sq = alpha * alpha;
+	const float one_minus_alpha_sq = 1.0f - alpha_sq;
+	const float cos_i = dot(normal, incoming);
+	const float tmp_a = alpha_sq + one_minus_alpha_sq * (cos_i * cos_i);
+	const float cos_o = dot(normal, outgoing);
+	const float tmp_b = alpha_sq + one_minus_alpha_sq * (cos_o * cos_o);
+	return 2.0f * cos_i * cos_o / (cos_o * sqrtf(tmp_a) + cos_i * sqrtf(tmp_b));
+}
+__device__ __forceinline__ float tr_g1(float alpha, V3 normal, V3 h, V3 v) // :80-89
+{
+	if (dot(v, h) / dot(v, normal) <= 0.0f)
+		return 0.0f;
+	const float c = dot(normal, v);
+	const float alpha_sq = alpha * alpha;
+	const float tmp = alpha_sq + (1.0f - alpha_sq) * (c * c);
+	return 2.0f * c / (sqrtf(tmp) + c);
+}
+__device__ __forceinline__ float tr_vndf(float a, V3 h, V3 incoming) // trowbridge_reitz_vndf.rs:9-15
+{
+	if (h.z < 0.0f)
+		return 0.0f;
+	return tr_g1(a, v3(0.0f, 0.0f, 1.0f), h, incoming) * fmax_(dot(incoming, h), 0.0f) * tr_d(a, h.z) / incoming.z;
+}
+__device__ inline V3 tr_sample_vndf(float a_x, float a_y, V3 incoming, rt_rng &rng) // :80-108
+{
+	const V3 vh = normalised(v3(a_x * incoming.x, a_y * incoming.y, incoming.z));
+	const float len_sq = vh.x * vh.x + vh.y * vh.y;
+	const V3 basis_two = len_sq > 0.0f ? v3(-vh.y, vh.x, 0.0f) / sqrtf(len_sq) : v3(1.0f, 0.0f, 0.0f);
+	const V3 basis_three = cross(vh, basis_two);
+	const float r = sqrtf(rt_rng_f32(&rng));
+	const float phi = kTau * rt_rng_f32(&rng);
+	const float tx = r * rt_cosf(phi);
+	float ty = r * rt_sinf(phi);
+	const float s = 0.5f * (1.0f + vh.z);
+	ty = (1.0f - s) * sqrtf(1.0f - tx * tx) + s * ty;
+	const V3 hh = tx * basis_two + ty * basis_three + sqrtf(fmax_(1.0f - tx * tx - ty * ty, 0.0f)) * vh;
+	return normalised(v3(a_x * hh.x, a_y * hh.y, fmax_(hh.z, 0.0f)));
+}
+__device__ inline V3 tr_sample(float alpha, V3 incoming, V3 normal, rt_rng &rng) // isotropic::sample :37-42
+{
+	const Coord coord = coord_from_z(normal);
+	const Coord inverse = coord_inverse(coord);
+	const V3 h = to_coord(coord, tr_sample_vndf(alpha, alpha, to_coord(inverse, incoming), rng));
+	return reflected(incoming, h);
+}
+__device__ inline float tr_pdf(float alpha, V3 incoming, V3 outgoing, V3 normal) // isotropic::pdf :44-54
+{
+	const Coord coord = coord_from_z(normal);
+	const Coord inverse = coord_inverse(coord);
+	incoming = to_coord(inverse, incoming);
+	outgoing = to_coord(inverse, outgoing);
+	V3 h = normalised(outgoing + incoming);
+	if (h.z < 0.0f)
+		h = -h;
+	return tr_vndf(alpha, h, incoming) / (4.0f * dot(incoming, h));
+}
+
+// ---- materials ----
+__device__ __forceinline__ V3 fresnel(float c, V3 f0) { return f0 + (1.0f - f0) * rt_pow5f(1.0f - c); } // refract.rs:59-61
+__device__ inline V3 tr_fresnel(const DevScene &S, const DevMaterial &m, const Hit &hit, V3 wo, V3 wi, V3 h) // trowbridge_reitz.rs:26-31
+{
+	const V3 ior = v3(m.ior[0], m.ior[1], m.ior[2]);
+	V3 f0 = vabs((1.0f - ior) / (1.0f + ior));
+	f0 = f0 * f0;
+	const V3 tex = texture_colour(S, m.texture, wi, hit.point);
+	f0 = (1.0f - m.metallic) * f0 + m.metallic * tex; // lerp :89-91
+	return fresnel(dot(wo, h), f0);
+}
+
+__device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return S.materials[mat].type == 0; }
+__device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
+{
+	const int t = S.materials[mat].type;
+	return t == 3 || t == 4;
+}
+
+__device__ __forceinline__ bool reflect_scatter(float fuzz, Ray &ray, const Hit &hit, rt_rng &rng) // reflect.rs:25-35
+{
+	V3 direction = -ray.d;
+	direction = reflected(direction, hit.normal);
+	const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+	const V3 ruv = random_unit_vector(rng);
+	ray = ray_new(point, direction + fuzz * ruv);
+	return false;
+}
+
+// Scatter::scatter_ray; returns `exit`
+__device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng)
+{
+	const DevMaterial &m = S.materials[mat];
+	const int type = m.type;
+	if (type == 1) { // Lambertian  lambertian.rs:30-41
+		const V3 direction = lambertian_sample(hit.normal, rng);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		ray = ray_new(point, direction);
+		return false;
+	}
+	if (type == 0) // Emit  emissive.rs:36-38
+		return true;
+	if (type == 3) // Reflect
+		return reflect_scatter(m.param, ray, hit, rng);
+	if (type == 4) { // Refract  refract.rs:26-50
+		const float eta = m.param;
+		float eta_fraction = 1.0f / eta;
+		if (!hit.out)
+			eta_fraction = eta;
+		const float cos_theta = fmin_(dot(-ray.d, hit.normal), 1.0f);
+		const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+		const bool cannot_refract = eta_fraction * sin_theta > 1.0f;
+		const float f0s = (1.0f - eta_fraction) / (1.0f + eta_fraction);
+		const V3 f0 = (f0s * f0s) * v3s(1.0f);
+		if (cannot_refract || fresnel(cos_theta, f0).x > rt_rng_f32(&rng))
+			return reflect_scatter(0.0f, ray, hit, rng);
+		const V3 perp = eta_fraction * (ray.d + cos_theta * hit.normal);
+		const V3 para = (-1.0f * sqrtf(fabsf(1.0f - mag_sq(perp)))) * hit.normal;
+		const V3 point = offset_ray(hit.point, hit.normal, hit.error, false);
+		ray = ray_new(point, perp + para);
+		return false;
+	}
+	if (type == 2) { // TrowbridgeReitz  trowbridge_reitz.rs:38-51
+		const V3 direction = tr_sample(m.param, -ray.d, hit.normal, rng);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		ray = ray_new(point, direction);
+		return false;
+	}
+	return true;
+}
+
+__device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+{
+	const DevMaterial &m = S.materials[mat];
+	if (m.type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
+		return fmax_(dot(wi, hit.normal), 0.0f) / kPi;
+	if (m.type == 2) { // trowbridge_reitz.rs:52-60
+		const float a = tr_pdf(m.param, -wo, wi, hit.normal);
+		return a == 0.0f ? INFINITY : a;
+	}
+	return 0.0f; // trait default (Reflect, Refract)
+}
+
+__device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+{
+	const DevMaterial &m = S.materials[mat];
+	if (m.type == 1) // lambertian.rs:45-47
+		return texture_colour(S, m.texture, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+	if (m.type == 3 || m.type == 4) // reflect.rs:36-38, refract.rs:51-53
+		return texture_colour(S, m.texture, wo, hit.point);
+	if (m.type == 2) { // trowbridge_reitz.rs:61-74
+		const V3 wom = -wo;
+		const V3 h = normalised(wi + wom);
+		if (dot(wi, hit.normal) < 0.0f || dot(h, wom) < 0.0f)
+			return v3s(0.0f);
+		const V3 f = tr_fresnel(S, m, hit, wom, wi, h);
+		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
+		const float d = tr_d(m.param, dot(hit.normal, h));
+		return f * g * d / (4.0f * fabsf(dot(wom, hit.normal)) * dot(wi, hit.normal));
+	}
+	return v3s(0.0f); // Emit::eval is unreachable!() in the reference
+}
+
+__device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+{
+	const DevMaterial &m = S.materials[mat];
+	if (m.type == 1) // lambertian.rs:48-50
+		return texture_colour(S, m.texture, wo, hit.point) * m.param;
+	if (m.type == 2) { // trowbridge_reitz.rs:75-87
+		const V3 wom = -wo;
+		const V3 h = normalised(wi + wom);
+		if (dot(wom, h) < 0.0f || dot(wi, hit.normal) < 0.0f)
+			return v3s(0.0f);
+		const V3 f = tr_fresnel(S, m, hit, wom, wi, h);
+		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
+		return f * g / tr_g1(m.param, hit.normal, h, wom);
+	}
+	// trait default: eval / scattering_pdf  (rt_core/src/material.rs:24-26)
+	return mat_eval(S, mat, hit, wo, wi) / mat_scattering_pdf(S, mat, hit, wo, wi);
+}
+
+__device__ __forceinline__ V3 mat_get_emission(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo)
+{
+	const DevMaterial &m = S.materials[mat];
+	if (m.type == 0) { // emissive.rs:23-26
+		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		return m.param * texture_colour(S, m.texture, wo, point);
+	}
+	return v3s(0.0f);
+}
+
+// ---- light-sampling geometry of primitives ----
+__device__ __forceinline__ float prim_area(const PrimGeom &g) // sphere.rs:167-169, triangle.rs:226-230
+{
+	if (g.type == kPrimSphere)
+		return 4.0f * kPi * g.p1.x * g.p1.x;
+	return 0.5f * mag(cross(g.p1 - g.p0, g.p2 - g.p0));
+}
+// sample_visible_from_point  sphere.rs:118-154, triangle.rs:231-241,263-277
+__device__ inline V3 prim_sample_visible_from_point(const PrimGeom &g, V3 in_point, rt_rng &rng)
+{
+	if (g.type == kPrimSphere) {
+		const V3 center = g.p0;
+		const float radius = g.p1.x;
+		const float distance_sq = mag_sq(in_point - center);
+		V3 point;
+		if (distance_sq <= radius * radius) { // Sphere::get_sample
+			const float z = 1.0f - 2.0f * rt_rng_f32(&rng);
+			const float a = sqrtf(fmax_(1.0f - z * z, 0.0f));
+			const float b = 2.0f * kPi * rt_rng_f32(&rng);
+			point = center + radius * v3(a * rt_cosf(b), a * rt_sinf(b), z);
+		} else {
+			const float distance = sqrtf(distance_sq);
+			const float sin_theta_max_sq = radius * radius / distance_sq;
+			const float cost_theta_max = sqrtf(fmax_(1.0f - sin_theta_max_sq, 0.0f));
+			const float r1 = rt_rng_f32(&rng);
+			const float cos_theta = (1.0f - r1) + r1 * cost_theta_max;
+			const float sin_theta = sqrtf(fmax_(1.0f - cos_theta * cos_theta, 0.0f));
+			const float phi = 2.0f * rt_rng_f32(&rng) * kPi;
+			const float ds = distance * cos_theta - sqrtf(fmax_(radius * radius - distance_sq * sin_theta * sin_theta, 0.0f));
+			const float cos_alpha = (distance_sq + radius * radius - ds * ds) / (2.0f * distance * radius);
+			const float sin_alpha = sqrtf(fmax_(1.0f - cos_alpha * cos_alpha, 0.0f));
+			const Coord cs = coord_from_z(normalised(in_point - center));
+			const V3 vec = to_coord(cs, v3(sin_alpha * rt_cosf(phi), sin_alpha * rt_sinf(phi), cos_alpha));
+			point = center + radius * vec;
+		}
+		return normalised(point - in_point);
+	}
+	const float su = sqrtf(rt_rng_f32(&rng));
+	const float u0 = 1.0f - su;
+	float r2 = rt_rng_f32(&rng);
+	if (g.type == kPrimMeshTriangle) // MeshTriangle takes a second sqrt (triangle.rs:270)
+		r2 = sqrtf(r2);
+	const float u1 = su * r2;
+	const V3 point = u0 * g.p0 + u1 * g.p1 + (1.0f - u0 - u1) * g.p2;
+	return normalised(point - in_point);
+}
+// Primitive::scattering_pdf  sphere.rs:155-166, triangle.rs:242-244,278-280
+__device__ __forceinline__ float prim_scattering_pdf(const PrimGeom &g, V3 hit_point, V3 wi, const Hit &sampled_hit)
+{
+	if (g.type == kPrimSphere) {
+		const float rsq = g.p1.x * g.p1.x;
+		const float dsq = mag_sq(hit_point - g.p0);
+		if (dsq <= rsq)
+			return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(wi, sampled_hit.normal)) * prim_area(g));
+		const float sin_theta_max_sq = rsq / dsq;
+		const float cos_theta_max = sqrtf(fmax_(1.0f - sin_theta_max_sq, 0.0f));
+		return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));
+	}
+	return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(sampled_hit.normal, wi)) * prim_area(g));
+}
+
+} // namespace rt

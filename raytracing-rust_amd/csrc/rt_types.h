@@ -1,0 +1,108 @@
+// rt_types.h -- how a scene lies in HBM for the gfx950 kernels.
+//
+// Host reference types (Node 64 B with Option<[usize;2]>, AllPrimitives ~88 B enum behind a
+// reference, Arc<MeshData> vertex indirection: SURVEY section 8) are re-laid-out for 64-lane
+// wavefronts:
+//   * DevNode (64 B, one 64-B-aligned record = four dwordx4 loads): an inner node carries the
+//     bounds of BOTH children, so one fetch decides both AABB tests of acceleration/mod.rs:
+//     208-210 and the child records are touched only when their box is hit.
+//   * DevPrim (48 B, three dwordx4): vertex positions are gathered out of MeshData at upload
+//     (no index chase during traversal); the type tag and material id ride in the spare .w lane.
+//   * DevShade (48 B): vertex normals, read once per ACCEPTED closest hit, never during traversal.
+//   * sky CDF rows (res_y x (res_x+1) floats) + marginal CDF: small enough for LDS (40.8 KB at the
+//     loader's default 100x100); the pdf table is not stored -- pdf[i] == cdf[i+1]-cdf[i] bit for
+//     bit, because that is how Distribution1D::new computes it (statistics/distributions.rs:32-38).
+#pragma once
+
+#include <stdint.h>
+#include "rt_vec.h"
+
+namespace rt {
+
+constexpr uint32_t kNoPrim = 0xFFFFFFFFu; // usize::MAX on the device side
+
+// child reference: >= 0 inner node index; < 0 leaf whose first primitive slot is ~ref
+struct alignas(64) DevNode {
+	float c0min[3], c0max[3];
+	float c1min[3], c1max[3];
+	int32_t c0, c1;
+	uint32_t n0, n1; // primitive counts when the child is a leaf
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
+
+enum : uint32_t { kPrimSphere = 0, kPrimTriangle = 1, kPrimMeshTriangle = 2 };
+
+// sphere:   a = (centre.xyz, meta)  b = (radius, 0, 0, 0)   c unused
+// triangle: a = (p0.xyz, meta)      b = (p1.xyz, 0)         c = (p2.xyz, 0)
+// meta = type | material << 2 (bit pattern stored in the float lane)
+struct alignas(16) DevPrim {
+	float a[4], b[4], c[4];
+};
+static_assert(sizeof(DevPrim) == 48, "DevPrim must be three 16-byte lanes");
+
+struct alignas(16) DevShade {
+	float n0[4], n1[4], n2[4]; // vertex normals (triangles); .w unused
+};
+
+struct DevMaterial {
+	int32_t type;
+	uint32_t texture;
+	float param;
+	float ior[3];
+	float metallic;
+	uint32_t pad;
+};
+
+struct DevTexture {
+	int32_t type;
+	float c1[3];
+	float c2[3];
+	uint32_t dim_x, dim_y;      // ImageTexture.dim = (w-1, h-1)
+	uint32_t pad;
+	const float *image;         // (dim_x+1)*(dim_y+1)*3
+	const float *perlin_vecs;   // 256*3
+	const uint32_t *perlin_perm; // 3*256
+};
+
+struct DevSky {
+	uint32_t texture, material;
+	uint32_t res_x, res_y;     // (0,0): not samplable
+	const float *row_cdf;      // res_y * (res_x+1)
+	const float *marginal_cdf; // res_y + 1
+};
+
+struct DevScene {
+	const DevNode *nodes;
+	const DevPrim *prims;
+	const DevShade *shade;
+	const uint32_t *prim_rank; // position of each primitive slot in reference BFS-leaf order
+	const DevMaterial *materials;
+	const DevTexture *textures;
+	const uint32_t *lights;    // Bvh.lights
+	uint32_t n_nodes, n_prims, n_lights, n_materials, n_textures;
+	int32_t root_is_leaf;      // the whole tree is one leaf node
+	float root_min[3], root_max[3];
+	uint32_t stack_depth;      // traversal stack entries per lane (tree depth + 1)
+	uint32_t has_triangles;
+	DevSky sky;
+};
+
+struct DevCamera {
+	float origin[3], lower_left[3], horizontal[3], vertical[3];
+};
+
+struct DevRenderParams {
+	uint32_t width, height;
+	uint32_t spp;
+	uint32_t sample_begin_lo, sample_begin_hi;
+	uint32_t seed_lo, seed_hi;
+	uint32_t max_depth, rr_threshold;
+	uint32_t shard_index, shard_count;
+	uint32_t tile_w, tile_h, tiles_x, tiles_y;
+	uint32_t n_work;          // pixels this launch owns (incl. out-of-image padding of edge tiles)
+	int32_t shard_layout;     // 1: packed shard output
+	int32_t prune;            // t-pruned traversal (validated equal to the reference's exhaustive one)
+	uint32_t sky_in_lds;      // sky CDF tables are staged in LDS
+};
+
+} // namespace rt

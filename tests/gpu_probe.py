@@ -1,0 +1,50 @@
+"""Ad-hoc GPU-vs-oracle probe (run on the GPU box): python tests/gpu_probe.py [scene] [W H SPP]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+pkg = importlib.import_module("raytracing-rust_amd")
+hb = importlib.import_module("raytracing-rust_amd.hip_backend")
+import oracle as O
+abi = pkg.abi
+
+def compare(name, a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    print(f"  {name}: max|d|={d.max():.3e} mean|d|={d.mean():.3e} n_diff={(a != b).sum()} / {a.size} bit_exact={np.array_equal(a, b)}")
+
+def main():
+    scene_name = sys.argv[1] if len(sys.argv) > 1 else "rtweekend1"
+    W, H, SPP = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (400, 225, 16)
+    ls = pkg.ssml.load_file(os.path.join(ROOT, "tests/golden/scenes", scene_name + ".ssml"))
+    print("devices:", hb.device_count())
+    t = time.time(); hs = hb.HipScene(ls.scene); print("scene create", time.time() - t)
+    os_ = O.Scene(ls.scene)
+    print("counts", hs.counts(), os_.counts())
+    print("nodes equal:", np.array_equal(hs.nodes(), os_.nodes()), "order equal:", np.array_equal(hs.primitive_order(), os_.primitive_order()),
+          "lights equal:", np.array_equal(hs.lights(), os_.lights()))
+    cam_h = hb.camera_new(**ls.camera_params); cam_o = O.camera_new(**ls.camera_params)
+    print("camera equal:", bytes(cam_h) == bytes(cam_o))
+    # hit records
+    rng = np.random.default_rng(1)
+    n = 20000
+    org = np.tile(np.array(ls.camera_params["origin"], dtype=np.float32), (n, 1))
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    hh = hs.check_hit(org, dirs); ho = os_.check_hit(org, dirs)
+    print("check_hit records equal:", hh.tobytes() == ho.tobytes(), " hits:", (ho["index"] != abi.NO_INDEX).sum())
+    if hh.tobytes() != ho.tobytes():
+        for f in hh.dtype.names:
+            if not np.array_equal(hh[f], ho[f], equal_nan=True):
+                bad = np.where(~np.all(np.atleast_2d((hh[f] == ho[f]).reshape(n, -1)), axis=1))[0]
+                print("   field", f, "differs at", bad[:5], hh[f][bad[:3]], ho[f][bad[:3]])
+    for method, mname in ((abi.RT_METHOD_NAIVE, "naive"), (abi.RT_METHOD_MIS, "mis")):
+        opts = abi.default_render_opts(W, H, SPP, method=method, seed=1)
+        t = time.time(); img_h, rays_h = hs.render(cam_h, opts); dt = time.time() - t
+        ms, _ = hs.last_kernel_ms()
+        t = time.time(); img_o, rays_o = os_.render(cam_o, opts); dto = time.time() - t
+        print(f"{mname}: hip wall {dt:.3f}s kernel {ms:.2f} ms ({W*H*SPP/ms/1e3:.1f} Msamples/s)  oracle {dto:.2f}s ({W*H*SPP/dto/1e6:.2f} Msamples/s)  rays {rays_h} vs {rays_o}")
+        compare(mname, img_h, img_o)
+        np.save(os.path.join(ROOT, "gpurun_out", f"probe_{scene_name}_{mname}_hip.npy"), img_h)
+
+if __name__ == "__main__":
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    main()
