@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the HIP path tracer on BASELINE.json's headline configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one complete render of scenes/rtweekend1.ssml at 1920x1080, 1024 spp, MIS, max_depth 50
+(BASELINE.json configs[1]) = 2.123 G samples, scene already resident in HBM.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the image's 8x8 tiles are interleaved over the ranks, every
+rank renders its tiles, and one RCCL gather per step assembles the frame on rank 0 (strong scaling:
+total work is fixed).  Rank 0 prints ONE JSON line.
+
+`roofline` prices the render kernel against HBM bandwidth with the ALGORITHMIC bytes of SURVEY 8(d)
+(counted by the oracle under the reference's traversal semantics: profiles/algorithmic_bytes.json,
+DESIGN.md section 5) and the kernel's own duration measured with HIP events on its launch stream.
+`cpu_baseline` times the CPU oracle (oracle/, a restatement of the reference's algorithm -- the Rust
+binary cannot be built in this pipeline) on this box's host cores on a bounded sample of the same
+workload.  The oracle is used for nothing else here.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP = 1920, 1080, 1024
+SCENE = "rtweekend1"
+SEED = 1
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# SURVEY 8(d) algorithmic bytes per sample for this workload, counted by tests/count_algorithmic_bytes.py
+# (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest hit, 64 B/sky op, 12 B/pixel)
+ALGORITHMIC_BYTES_PER_SAMPLE = 446.77
+
+
+def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=12.0):
+    """Time the CPU oracle on a bounded sample: same scene, resolution, seed and method, fewer spp."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O  # the ONLY use of oracle/ in this file: the reported CPU baseline
+    abi = pkg.abi
+    cores = os.cpu_count() or 1
+    s = O.Scene(scene_desc)
+    cam = O.camera_new(**camera_params)
+    t0 = time.time()
+    s.render(cam, abi.default_render_opts(WIDTH, HEIGHT, 1, seed=SEED), n_threads=cores)
+    per_spp = max(time.time() - t0, 1e-3)
+    spp = int(max(2, min(64, target_seconds / per_spp)))
+    t0 = time.time()
+    s.render(cam, abi.default_render_opts(WIDTH, HEIGHT, spp, seed=SEED), n_threads=cores)
+    dt = time.time() - t0
+    return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{SCENE}.ssml {WIDTH}x{HEIGHT}, {spp} of {SPP} spp, MIS, max_depth 50, {dt:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP back end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = importlib.import_module("raytracing-rust_amd")
+    hb = importlib.import_module("raytracing-rust_amd.hip_backend")
+    D = importlib.import_module("raytracing-rust_amd.distributed")
+    abi = pkg.abi
+
+    ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".ssml"))
+    t0 = time.time()
+    scene = hb.HipScene(ls.scene, device=local_rank)  # BVH build + upload: not part of the timed region
+    build_s = time.time() - t0
+    cam = hb.camera_new(**ls.camera_params)
+
+    opts = abi.default_render_opts(WIDTH, HEIGHT, SPP, method=abi.RT_METHOD_MIS, seed=SEED)
+    sopts = D.shard_opts(opts, rank, world)
+    gather = D.ShardGather(opts, rank, world, device)
+    shard = gather.new_shard_buffer()
+    frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=device) if rank == 0 else None
+    d_rays = torch.zeros(1, dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        scene.render_device(cam, sopts, shard.data_ptr(), d_rays.data_ptr(), stream.cuda_stream)
+        return gather.gather(shard, frame)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded around the kernel on its launch stream; reading them waits for that
+        # kernel only, which the next step's launch on the same stream would do anyway
+        kernel_ms.append(scene.last_kernel_ms()[0])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rays = D.reduce_rays(d_rays.clone(), world)
+
+    if rank == 0:
+        samples_per_step = WIDTH * HEIGHT * SPP
+        value = samples_per_step * args.steps / elapsed / 1e6
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        # the dominant (only) kernel: one render launch per step on this rank, covering 1/world of the samples
+        launch_samples = samples_per_step / world
+        achieved = ALGORITHMIC_BYTES_PER_SAMPLE * launch_samples / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp) and world == 1:
+            traffic = json.load(open(tp)).get(f"{SCENE}_{WIDTH}x{HEIGHT}x{SPP}_mis", {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp",
+            "value": value,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"scenes/{SCENE}.ssml {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={SEED}",
+                       "parallelism": f"tile-sharded x{world}, replicated BVH, one RCCL gather per frame" if world > 1 else "1 GPU",
+                       "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
+                       "scene_build_s": build_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "rt::render_kernel<1,false,true>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE,
+                         "note": "algorithmic (requested) bytes under reference traversal semantics; the 2-sphere scene and "
+                                 "its 41 KB sky table live in LDS/L1/L2, so real HBM traffic is ~12 B/pixel (see traffic) and "
+                                 "this kernel is VALU/latency-bound, not HBM-bound, by design"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, ls.scene, ls.camera_params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

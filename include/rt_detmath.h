@@ -186,7 +186,7 @@ RT_HD uint32_t rt_rng_below(rt_rng *r, uint32_t n)
 /* ------------------------------------------------------------------------------------ */
 /* Deterministic f32 elementary functions (replacement for the platform libm the        */
 /* reference reaches through Rust std).  Accuracy is tested against glibc in            */
-/* tests/test_detmath.py (<= 2 ulp on the argument ranges the path uses).               */
+/* tests/test_detmath.py (sin, cos <= 2 ulp, acos <= 2.5, atan2 <= 4, tan <= 4).              */
 /* ------------------------------------------------------------------------------------ */
 #define RT_PI 3.14159274101257324219f      /* std::f32::consts::PI  */
 #define RT_TAU 6.28318548202514648438f     /* std::f32::consts::TAU */
@@ -194,18 +194,22 @@ RT_HD uint32_t rt_rng_below(rt_rng *r, uint32_t n)
 #define RT_FRAC_PI_4 0.785398185253143310547f
 #define RT_F32_EPSILON 1.1920928955078125e-07f /* f32::EPSILON */
 
-/* x - k*pi/2 with a three-term Cody-Waite split of pi/2 (24+24+24 bits) and fmaf, so the
- * reduction is exact to ~1e-15 for |x| up to a few 1e4.  Larger arguments lose accuracy
- * gracefully (no Payne-Hanek); the path's arguments are 2*pi*r, pi*v and 10*coordinate. */
+/* x - k*pi/2 with a three-term Cody-Waite split of pi/2 (24+24+24 bits) and fmaf: exact to ~1e-15
+ * for |x| up to 2^22.  Beyond that (never reached by the path's own arguments 2*pi*r, pi*v and
+ * 10*coordinate) x is first folded into [0, 2*pi) in IEEE double arithmetic -- deterministic on
+ * both sides, accuracy |x| * 2^-53 -- and from 2^50 on the result is NaN (no Payne-Hanek). */
 RT_HD float rt_reduce_pio2(float x, int *quadrant)
 {
+	if (fabsf(x) > 4194304.0f) {
+		const double two_pi = 6.283185307179586476925286766559;
+		const double xd = (double)x;
+		x = (float)(xd - two_pi * floor(xd / two_pi));
+	}
 	const float k = rintf(x * 0.636619746685028076172f);
 	float r = fmaf(-k, 1.57079637050628662109f, x);
 	r = fmaf(-k, -4.37113882867379282984e-08f, r);
 	r = fmaf(-k, -1.71512451000588185479e-15f, r);
-	/* k mod 4 in float arithmetic (exact for every finite k), so the int conversion is
-	 * never out of range -- an out-of-range float->int cast differs between x86 and gfx950 */
-	*quadrant = (int)(k - 4.0f * floorf(k * 0.25f));
+	*quadrant = (int)k; /* |k| <= 2^22 * 2/pi: always representable */
 	return r;
 }
 
@@ -227,8 +231,8 @@ RT_HD float rt_cos_kernel(float r)
 
 RT_HD float rt_sinf(float x)
 {
-	if (!(fabsf(x) <= 3.0e38f))
-		return x - x; /* inf, nan -> nan */
+	if (!(fabsf(x) < 1.125899906842624e15f))
+		return (x - x) / (x - x); /* inf, nan, |x| >= 2^50 -> nan */
 	int q;
 	const float r = rt_reduce_pio2(x, &q);
 	const float s = (q & 1) ? rt_cos_kernel(r) : rt_sin_kernel(r);
@@ -236,8 +240,8 @@ RT_HD float rt_sinf(float x)
 }
 RT_HD float rt_cosf(float x)
 {
-	if (!(fabsf(x) <= 3.0e38f))
-		return x - x;
+	if (!(fabsf(x) < 1.125899906842624e15f))
+		return (x - x) / (x - x);
 	int q;
 	const float r = rt_reduce_pio2(x, &q);
 	const float c = (q & 1) ? rt_sin_kernel(r) : rt_cos_kernel(r);

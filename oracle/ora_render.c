@@ -898,3 +898,24 @@ int ora_offset_ray(const float origin[3], const float normal[3], const float err
 	out[2] = r.z;
 	return RT_OK;
 }
+
+/* raw Philox4x32-10 block (for the Random123 known-answer vectors) */
+int ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+	uint32_t c[4] = { ctr[0], ctr[1], ctr[2], ctr[3] };
+	rt_philox4x32_10(c, key[0], key[1]);
+	memcpy(out, c, sizeof c);
+	return RT_OK;
+}
+
+/* Coordinate::new_from_z(z) then to_coord / inverse.to_coord (utility/coord.rs:9-31) */
+int ora_coord_apply(const float z[3], const float v[3], int32_t inverse, float out[3])
+{
+	const ora_coord c = ora_coord_new_from_z(v3_from(z));
+	const ora_coord inv = ora_coord_create_inverse(&c);
+	const vec3 r = ora_coord_to_coord(inverse ? &inv : &c, v3_from(v));
+	out[0] = r.x;
+	out[1] = r.y;
+	out[2] = r.z;
+	return RT_OK;
+}

@@ -253,3 +253,17 @@ def offset_ray(origin, normal, error, is_brdf=True):
     out = (C.c_float * 3)()
     _check(lib().ora_offset_ray(_f3(origin), _f3(normal), _f3(error), C.c_int32(1 if is_brdf else 0), out))
     return np.array(list(out), dtype=np.float32)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    _check(lib().ora_philox4x32_10(c, k, out))
+    return [int(x) for x in out]
+
+
+def coord_apply(z, v, inverse=False):
+    out = (C.c_float * 3)()
+    _check(lib().ora_coord_apply(_f3(z), _f3(v), C.c_int32(1 if inverse else 0), out))
+    return np.array(list(out), dtype=np.float32)

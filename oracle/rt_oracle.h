@@ -80,6 +80,8 @@ int ora_sort_by_indices(uint64_t *values, uint64_t n, const uint64_t *indices);
 int ora_sky_tables(const ora_scene *scene, float *row_cdf, float *marginal_cdf);
 /* utility helpers, elementwise: which = 0 next_float, 1 previous_float, 2 gamma(n = (uint)a) */
 int ora_utility_eval(int32_t which, const float *a, uint64_t n, float *out);
+int ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int ora_coord_apply(const float z[3], const float v[3], int32_t inverse, float out[3]);
 int ora_offset_ray(const float origin[3], const float normal[3], const float error[3], int32_t is_brdf, float out[3]);
 
 #ifdef __cplusplus

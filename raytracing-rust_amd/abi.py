@@ -173,7 +173,7 @@ EXPECTED_SIZES = {
     "rt_triangle_data": (TriangleData, 72),
     "rt_mesh_desc": (MeshDesc, 32),
     "rt_sky_desc": (SkyDesc, 16),
-    "rt_scene_desc": (SceneDesc, 88),
+    "rt_scene_desc": (SceneDesc, 96),
     "rt_camera": (Camera, 48),
     "rt_render_opts": (RenderOpts, 72),
     "rt_hit_record": (HitRecord, 72),
