@@ -6,9 +6,9 @@
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg to CHECK the HIP back end.
  * Nothing under raytracing-rust_amd/ includes, links or calls it.
  *
- * Parity status: the reference cannot be built here (no Rust toolchain, nightly-only,
- * no Cargo.lock) and is unseeded, and it ships no golden images or hit-record vectors.
- * The oracle is therefore pinned by (a) the analytic targets of the reference's
+ * PARITY STATUS: pixel-level parity with the Rust binary is "parity unpinned" -- the reference
+ * cannot be built here (no Rust toolchain, nightly-only, no Cargo.lock), is unseeded, and ships
+ * no golden images, hit records or seeded vectors.  What does pin the oracle is (a) the analytic targets of the reference's
  * (commented-out) integration tests -- furnace = 0.25, MIS == naive -- (b) restated
  * statistical sampler tests, (c) hand-derivable pixels (primary sky misses), and (d) the
  * reference's one deterministic unit test (sort_by_indices).  See DESIGN.md section 3.
