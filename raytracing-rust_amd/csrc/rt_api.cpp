@@ -18,8 +18,8 @@
 
 namespace rt {
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_block);
-hipError_t render_occupancy(int method, bool prune, bool sky_lds, size_t lds_bytes, int *blocks_per_cu);
-hipError_t launch_render(int method, bool prune, bool sky_lds, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
+hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter);
 hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
@@ -61,6 +61,7 @@ struct rt_scene {
 	uint32_t n_launches = 0;
 	int n_cus = 0;
 	int traversal_mode = -1; // -1 auto, 0 exhaustive (reference order of work), 1 pruned
+	int feature_set = 2;     // smallest kernel variant covering the scene: 0 spheres-only, 1 simple, 2 full
 	size_t max_lds = 65536;
 };
 
@@ -214,6 +215,24 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if (hipStreamCreate(&s->stream) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
 	if (hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
 		return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+	{ // which kernel variant covers this scene (rt_types.h Feat)
+		bool cmat = false, ctex = false;
+		for (const DevMaterial &m : h.materials)
+			cmat = cmat || (m.type != RT_MAT_EMIT && m.type != RT_MAT_LAMBERTIAN);
+		for (const DevTexture &t : h.textures)
+			ctex = ctex || (t.type != RT_TEX_SOLID && t.type != RT_TEX_LERP);
+		if (cmat || ctex)
+			s->feature_set = 2;
+		else if (h.has_triangles || !h.lights.empty())
+			s->feature_set = 1;
+		else
+			s->feature_set = 0;
+		if (const char *e = std::getenv("RT_HIP_FEATURE_SET")) { // force a LARGER variant (debugging / tests)
+			const int f = std::atoi(e);
+			if (f > s->feature_set && f <= 2)
+				s->feature_set = f;
+		}
+	}
 	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
 		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
 		if (std::strcmp(e, "pruned") == 0) s->traversal_mode = 1;
@@ -386,7 +405,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks + sky tables exceed the LDS of one CU");
 
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, sky_lds, lds_bytes, &blocks_per_cu));
+	HIP_TRY(render_occupancy(o->render_method, prune, sky_lds, s->feature_set, lds_bytes, &blocks_per_cu));
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
@@ -409,7 +428,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	std::memcpy(cam.vertical, camera->vertical, 12);
 
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
-	HIP_TRY(launch_render(o->render_method, prune, sky_lds, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, d_out_rgb,
+	HIP_TRY(launch_render(o->render_method, prune, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, d_out_rgb,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	s->timed = true;

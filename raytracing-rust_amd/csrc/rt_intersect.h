@@ -24,19 +24,23 @@ struct Ray {
 };
 
 // Ray::new  ray.rs:13-46 (time is carried nowhere: it is never read on the render path)
-__device__ __forceinline__ Ray ray_new(V3 origin, V3 direction)
+template <class F> __device__ __forceinline__ Ray ray_new(V3 origin, V3 direction)
 {
 	Ray r;
 	direction = direction / mag(direction);
-	const float ax = fabsf(direction.x), ay = fabsf(direction.y), az = fabsf(direction.z);
-	// max_axis 0 (x dominant) and 1 (y dominant) BOTH swap x<->z (ray.rs:26-33)
-	const bool swap = (ax > ay && ax > az) || (ay > az);
-	const float sx = swap ? direction.z : direction.x;
-	const float sz = swap ? direction.x : direction.z;
 	r.o = origin;
 	r.d = direction;
 	r.inv = v3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
-	r.shear = v3(-sx / sz, -direction.y / sz, 1.0f / sz);
+	if (F::tri) {
+		const float ax = fabsf(direction.x), ay = fabsf(direction.y), az = fabsf(direction.z);
+		// max_axis 0 (x dominant) and 1 (y dominant) BOTH swap x<->z (ray.rs:26-33)
+		const bool swap = (ax > ay && ax > az) || (ay > az);
+		const float sx = swap ? direction.z : direction.x;
+		const float sz = swap ? direction.x : direction.z;
+		r.shear = v3(-sx / sz, -direction.y / sz, 1.0f / sz);
+	} else {
+		r.shear = v3s(0.0f); // only triangle_intersection reads the shear (triangle.rs:113-123)
+	}
 	return r;
 }
 __device__ __forceinline__ bool ray_swaps_xz(const Ray &r) // Axis::get_max_abs_axis + swap_z  primitives/mod.rs:62-82
@@ -166,7 +170,7 @@ struct PrimGeom {
 	uint32_t type, material;
 	V3 p0, p1, p2; // sphere: p0 = centre, p1.x = radius
 };
-__device__ __forceinline__ PrimGeom load_prim(const DevScene &S, uint32_t slot)
+template <class F> __device__ __forceinline__ PrimGeom load_prim(const DevScene &S, uint32_t slot)
 {
 	const float4 *q = reinterpret_cast<const float4 *>(&S.prims[slot]);
 	const float4 a = q[0];
@@ -177,7 +181,7 @@ __device__ __forceinline__ PrimGeom load_prim(const DevScene &S, uint32_t slot)
 	g.material = meta >> 2;
 	g.p0 = v3(a.x, a.y, a.z);
 	g.p1 = v3(b.x, b.y, b.z);
-	if (g.type != kPrimSphere) {
+	if (F::tri && g.type != kPrimSphere) {
 		const float4 c = q[2];
 		g.p2 = v3(c.x, c.y, c.z);
 	} else {
@@ -186,9 +190,9 @@ __device__ __forceinline__ PrimGeom load_prim(const DevScene &S, uint32_t slot)
 	return g;
 }
 // Primitive::get_int reduced to (hit?, t)
-__device__ __forceinline__ bool prim_t(const PrimGeom &g, const Ray &r, float &t)
+template <class F> __device__ __forceinline__ bool prim_t(const PrimGeom &g, const Ray &r, float &t)
 {
-	if (g.type == kPrimSphere)
+	if (!F::tri || g.type == kPrimSphere)
 		return sphere_t(g.p0, g.p1.x, r, t);
 	float b0, b1, b2;
 	return triangle_t(g.p0, g.p1, g.p2, r, t, b0, b1, b2);
@@ -213,15 +217,15 @@ __device__ __forceinline__ bool check_side(V3 &normal, V3 ray_direction)
 }
 
 // the rest of Sphere::get_int (sphere.rs:79-101) / triangle_intersection (triangle.rs:179-215)
-// for the primitive that won the traversal; recomputes t with the same code, so the value is the
-// one the traversal compared.
-__device__ __forceinline__ void make_hit(const DevScene &S, uint32_t slot, const Ray &r, Hit &h, uint32_t &material)
+// for the primitive that won the traversal.  `t` is the value the traversal computed for it; a
+// sphere needs nothing else, a triangle re-runs its intersector for the barycentrics (same code and
+// inputs, so the same t).
+template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, uint32_t slot, const Ray &r, float t_known, Hit &h, uint32_t &material)
 {
-	const PrimGeom g = load_prim(S, slot);
+	const PrimGeom g = load_prim<F>(S, slot);
 	material = g.material;
-	if (g.type == kPrimSphere) {
-		float t = 0.0f;
-		(void)sphere_t(g.p0, g.p1.x, r, t);
+	if (!F::tri || g.type == kPrimSphere) {
+		const float t = t_known;
 		const V3 point = r.o + r.d * t;
 		V3 normal = (point - g.p0) / g.p1.x;
 		bool out = true;
@@ -303,13 +307,13 @@ __device__ __forceinline__ float box_extent_l1(const float mn[3], const float mx
 }
 
 // Bvh::check_hit's selection rule over a leaf  mod.rs:270-293
-__device__ __forceinline__ void closest_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float &best_t,
+template <class F> __device__ __forceinline__ void closest_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float &best_t,
                                              uint32_t &best_prim)
 {
 	for (uint32_t slot = first; slot < first + count; ++slot) {
-		const PrimGeom g = load_prim(S, slot);
+		const PrimGeom g = load_prim<F>(S, slot);
 		float t;
-		if (prim_t(g, r, t) && t > 0.0f) {
+		if (prim_t<F>(g, r, t) && t > 0.0f) {
 			bool take;
 			if (best_prim == kNoPrim)
 				take = true;
@@ -327,7 +331,7 @@ __device__ __forceinline__ void closest_leaf(const DevScene &S, const Ray &r, ui
 	}
 }
 
-template <bool PRUNE>
+template <class F, bool PRUNE>
 __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
 {
 	best_t = 0.0f;
@@ -336,7 +340,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
 		return;
 	if (S.root_is_leaf) {
-		closest_leaf(S, r, 0, S.n_prims, best_t, best_prim);
+		closest_leaf<F>(S, r, 0, S.n_prims, best_t, best_prim);
 		return;
 	}
 	int sp = 0;
@@ -350,7 +354,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 			if (h0 && h1 && t1 < t0 && n.c0 < 0 && n.c1 < 0) {
 				// two leaves: test the nearer first so the farther may be pruned
 				if (!(best_prim != kNoPrim && t1 - kPruneSlack * (fabsf(t1) + fabsf(best_t) + box_extent_l1(n.c1min, n.c1max)) > best_t))
-					closest_leaf(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
+					closest_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
 				h1 = false;
 			}
 			if (h0 && best_prim != kNoPrim &&
@@ -358,7 +362,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 				h0 = false;
 		}
 		if (h0 && n.c0 < 0) {
-			closest_leaf(S, r, (uint32_t)~n.c0, n.n0, best_t, best_prim);
+			closest_leaf<F>(S, r, (uint32_t)~n.c0, n.n0, best_t, best_prim);
 			h0 = false;
 		}
 		if (PRUNE) {
@@ -367,7 +371,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 				h1 = false;
 		}
 		if (h1 && n.c1 < 0) {
-			closest_leaf(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
+			closest_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
 			h1 = false;
 		}
 		if (h0 && h1) {
@@ -396,27 +400,27 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 // returning an index != usize::MAX, mis.rs:104-115) and Bvh::check_hit_index (mod.rs:244-261):
 // some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
 // limit" (any t > 0 occludes).
-__device__ __forceinline__ bool any_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float t_limit, uint32_t skip)
+template <class F> __device__ __forceinline__ bool any_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float t_limit, uint32_t skip)
 {
 	for (uint32_t slot = first; slot < first + count; ++slot) {
 		if (slot == skip)
 			continue;
-		const PrimGeom g = load_prim(S, slot);
+		const PrimGeom g = load_prim<F>(S, slot);
 		float t;
-		if (prim_t(g, r, t) && t > 0.0f && !(t >= t_limit))
+		if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
 			return true;
 	}
 	return false;
 }
 
-template <bool PRUNE>
+template <class F, bool PRUNE>
 __device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
 {
 	float tm;
 	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
 		return false;
 	if (S.root_is_leaf)
-		return any_leaf(S, r, 0, S.n_prims, t_limit, skip);
+		return any_leaf<F>(S, r, 0, S.n_prims, t_limit, skip);
 	int sp = 0;
 	uint32_t node = 0;
 	for (;;) {
@@ -431,12 +435,12 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint3
 				h1 = false;
 		}
 		if (h0 && n.c0 < 0) {
-			if (any_leaf(S, r, (uint32_t)~n.c0, n.n0, t_limit, skip))
+			if (any_leaf<F>(S, r, (uint32_t)~n.c0, n.n0, t_limit, skip))
 				return true;
 			h0 = false;
 		}
 		if (h1 && n.c1 < 0) {
-			if (any_leaf(S, r, (uint32_t)~n.c1, n.n1, t_limit, skip))
+			if (any_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, t_limit, skip))
 				return true;
 			h1 = false;
 		}

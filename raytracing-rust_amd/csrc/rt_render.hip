@@ -14,11 +14,16 @@
 // 1..49 bounces, so lanes of a wavefront finish samples at different times; a finished lane
 // immediately regenerates the next sample (or pulls the next pixel from a global queue with one
 // wave-aggregated atomic: __ballot + popcount + one atomicAdd per wave) instead of idling until
-// the longest path of the wave ends.  Every loop iteration is one bounce for all 64 lanes:
-//   [A] closest-hit walk of the lane's current ray (camera ray or bounce ray)
-//   [B] shade: emission, MIS weight, Russian roulette, or sample finished
-//   [C] light sample (sky table in LDS / light primitive) + any-hit shadow walk
-//   [D] BSDF sample -> next bounce ray
+// the longest path of the wave ends.  A bounce has two halves:
+//   TRACE phase  [A] closest-hit walk of the lane's current ray (camera ray or bounce ray)
+//                [B] shade: emission, MIS weight, Russian roulette, or sample finished
+//   LIGHT phase  [C] light sample (sky table in LDS / light primitive) + any-hit shadow walk
+//                [D] BSDF sample -> next bounce ray
+// About half of all [B] outcomes end the sample (the ray left for the sky), so running A-B-C-D in
+// lockstep leaves those lanes idle through C-D.  Instead every iteration the wave votes
+// (__ballot/popcount) and runs the phase most of its lanes wait for; finished lanes regenerate and
+// stay in the TRACE phase while continuing paths pile up for the LIGHT phase.  Paths never read
+// each other's state and each owns its random stream, so the schedule cannot change a pixel.
 // Scene data is read-only and shared: BVH / primitives through L1/L2 from HBM, the sky's CDF rows
 // staged once per workgroup into LDS next to the per-lane traversal stacks.  HBM write traffic is
 // 12 bytes per pixel for the whole render.  No MFMA: nothing here is a dense contraction.
@@ -26,7 +31,12 @@
 
 namespace rt {
 
-enum : int { ST_NEED_PIXEL = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+enum : int { ST_NEED_PIXEL = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_LIGHT = 3, ST_DONE = 4 };
+// the LIGHT phase runs once this many lanes of the wave wait for it (or nobody wants the TRACE phase)
+#ifndef RT_LIGHT_PHASE_THRESHOLD
+#define RT_LIGHT_PHASE_THRESHOLD 32
+#endif
+constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 
 __device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt_core/src/lib.rs:36-40
 {
@@ -58,7 +68,7 @@ __device__ __forceinline__ bool lights_contain(const DevScene &S, uint32_t prim)
 	return false;
 }
 
-template <int METHOD, bool PRUNE, bool SKY_LDS>
+template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
 __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
@@ -111,6 +121,27 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 	unsigned long long rays_total = 0;
 	bool primary = true;
 
+	// sample finished: filter, fold into the running mean, next sample or next pixel
+	auto finalize = [&](bool filter) {
+		V3 c = outp;
+		if (filter && (contains_nan(c) || !is_finite_any(c))) // integrators/mod.rs:74-76, mis.rs:88-90
+			c = v3s(0.0f);
+		const float i_f = (float)(sample_local + 1u);
+		mean.x += (c.x - mean.x) / i_f; // src/main.rs:179-185
+		mean.y += (c.y - mean.y) / i_f;
+		mean.z += (c.z - mean.z) / i_f;
+		rays_total += ray_count;
+		sample_local += 1;
+		if (sample_local == P.spp) {
+			out[3u * (size_t)out_index + 0u] = mean.x;
+			out[3u * (size_t)out_index + 1u] = mean.y;
+			out[3u * (size_t)out_index + 2u] = mean.z;
+			st = ST_NEED_PIXEL;
+		} else {
+			st = ST_NEW_SAMPLE;
+		}
+	};
+
 	for (;;) {
 		// ---- work acquisition: one atomic per wave for all lanes that ran out of samples ----
 		{
@@ -136,143 +167,157 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 				}
 			}
 		}
-		if (__ballot(st != ST_DONE) == 0ull)
-			break;
-
-		// ---- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61 ----
-		if (st == ST_NEW_SAMPLE) {
-			rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
-			const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
-			const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
-			// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
-			ray = ray_new(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
-			(void)rt_rng_f32(&rng);
-			thr = v3s(1.0f);
-			outp = v3s(0.0f);
-			depth = 0;
-			ray_count = 0;
-			primary = true;
-			st = ST_TRACE;
+		// ---- phase vote.  Lanes want either the TRACE phase ([A] closest hit + [B] shade; a lane
+		// whose sample ended regenerates and stays in this phase) or the LIGHT phase ([C] light sample
+		// + shadow walk, [D] BSDF sample).  The wave runs the phase the majority waits for, the others
+		// keep their state in registers: no lane idles through a phase it has no work in. ----
+		const uint32_t n_light = (uint32_t)__popcll(__ballot(st == ST_LIGHT));
+		const uint32_t n_trace = (uint32_t)__popcll(__ballot(st == ST_NEW_SAMPLE || st == ST_TRACE));
+		if (n_light + n_trace == 0u) {
+			if (__ballot(st == ST_NEED_PIXEL) == 0ull)
+				break; // every lane is ST_DONE
+			continue;  // only edge-tile padding was handed out: ask again
 		}
-		const bool act = (st == ST_TRACE);
+		const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
 
-		// ---- [A] Bvh::check_hit for the lane's current ray ----
-		float best_t = 0.0f;
-		uint32_t prim = kNoPrim;
-		if (act)
-			trace_closest<PRUNE>(S, ray, stk, best_t, prim);
-
-		bool finish = false;
-		bool filter = true; // apply the NaN / non-finite filter (integrators/mod.rs:74-76, mis.rs:88-90)
-
-		if (act) {
-			Hit nh;
-			uint32_t nmat;
-			if (prim != kNoPrim)
-				make_hit(S, prim, ray, nh, nmat);
-			else
-				make_sky_hit(S, nh, nmat);
-
-			if (METHOD == 0) {
-				// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
-				ray_count += 1;
-				const V3 wo_n = ray.d;
-				const V3 emission = mat_get_emission(S, nmat, nh, wo_n);
-				const bool exit = mat_scatter_ray(S, nmat, ray, nh, rng);
-				if (depth == 0) {
-					outp = outp + emission;
-					if (exit)
-						finish = true;
-				}
-				if (!finish && exit) {
-					outp = outp + thr * emission;
-					finish = true;
-				}
-				if (!finish) {
-					if (!mat_is_delta(S, nmat))
-						thr = thr * mat_eval_over_pdf(S, nmat, nh, wo_n, ray.d);
-					else
-						thr = thr * mat_eval(S, nmat, nh, wo_n, ray.d);
-					if (depth > P.rr_threshold) {
-						const float p = component_max(thr);
-						if (rt_rng_f32(&rng) > p)
-							finish = true;
-						else
-							thr = thr / p;
-					}
-					if (!finish) {
-						depth += 1;
-						if (!(depth < P.max_depth))
-							finish = true;
-					}
-				}
-			} else if (primary) {
-				// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
-				wo = ray.d;
-				hit = nh;
-				mat = nmat;
-				const V3 emission = mat_get_emission(S, mat, hit, wo);
-				Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
-				const bool exit = mat_scatter_ray(S, mat, clone, hit, rng);
-				outp = outp + emission;
-				if (exit) {
-					finish = true;
-					filter = false; // mis.rs:29-31 returns before the filter
-				} else {
-					depth = 1;
-					primary = false;
-					if (!(depth < P.max_depth))
-						finish = true;
-				}
-			} else {
-				// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
-				const V3 m_wi = ray.d;
-				const float m_pdf = mat_scattering_pdf(S, mat, hit, wo, m_wi);
-				const V3 le = mat_get_emission(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
-				thr = thr * mat_eval_over_pdf(S, mat, hit, wo, m_wi);
-				if (!is_zero(le)) {
-					const bool on_light = (prim != kNoPrim) && lights_contain(S, prim) && !mat_is_delta(S, mat);
-					if (on_light || (prim == kNoPrim && sky_samplable)) {
-						// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
-						const float divisor = (float)(sky_samplable ? S.n_lights + 1u : S.n_lights);
-						float l_pdf;
-						if (prim == kNoPrim) {
-							l_pdf = sky_pdf(S, T, m_wi) / divisor;
-						} else {
-							const PrimGeom g = load_prim(S, prim);
-							l_pdf = prim_scattering_pdf(g, hit.point, m_wi, nh) / divisor;
-						}
-						const float mis_weight = power_heuristic(m_pdf, l_pdf);
-						outp = outp + thr * le * mis_weight;
-					} else {
-						outp = outp + thr * le;
-					}
-				}
-				if (mat_is_light(S, nmat)) {
-					finish = true;
-				} else {
-					if (depth > P.rr_threshold) {
-						const float p = component_max(thr);
-						if (rt_rng_f32(&rng) > p)
-							finish = true;
-						else
-							thr = thr / p;
-					}
-					if (!finish) {
-						wo = m_wi;
-						hit = nh;
-						mat = nmat;
-						depth += 1;
-						if (!(depth < P.max_depth))
-							finish = true;
-					}
-				}
+		if (!run_light) {
+			// ---- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61 ----
+			if (st == ST_NEW_SAMPLE) {
+				rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
+				const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
+				const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
+				// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
+				ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
+				(void)rt_rng_f32(&rng);
+				thr = v3s(1.0f);
+				outp = v3s(0.0f);
+				depth = 0;
+				ray_count = 0;
+				primary = true;
+				st = ST_TRACE;
 			}
-		}
+			const bool act = (st == ST_TRACE);
 
-		if (METHOD == 1) {
-			// ---- [C] sample_lights  mis.rs:95-157, for lanes whose path continues ----
-			const bool cont = act && !finish;
+			// ---- [A] Bvh::check_hit for the lane's current ray ----
+			float best_t = 0.0f;
+			uint32_t prim = kNoPrim;
+			if (act)
+				trace_closest<F, PRUNE>(S, ray, stk, best_t, prim);
+
+			if (act) {
+				bool finish = false;
+				bool filter = true;
+				Hit nh;
+				uint32_t nmat;
+				if (prim != kNoPrim)
+					make_hit<F>(S, prim, ray, best_t, nh, nmat);
+				else
+					make_sky_hit(S, nh, nmat);
+
+				if (METHOD == 0) {
+					// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
+					ray_count += 1;
+					const V3 wo_n = ray.d;
+					const V3 emission = mat_get_emission<F>(S, nmat, nh, wo_n);
+					const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng);
+					if (depth == 0) {
+						outp = outp + emission;
+						if (exit)
+							finish = true;
+					}
+					if (!finish && exit) {
+						outp = outp + thr * emission;
+						finish = true;
+					}
+					if (!finish) {
+						if (!mat_is_delta<F>(S, nmat))
+							thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d);
+						else
+							thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d);
+						if (depth > P.rr_threshold) {
+							const float p = component_max(thr);
+							if (rt_rng_f32(&rng) > p)
+								finish = true;
+							else
+								thr = thr / p;
+						}
+						if (!finish) {
+							depth += 1;
+							if (!(depth < P.max_depth))
+								finish = true;
+						}
+					}
+				} else if (primary) {
+					// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
+					wo = ray.d;
+					hit = nh;
+					mat = nmat;
+					const V3 emission = mat_get_emission<F>(S, mat, hit, wo);
+					Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
+					const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng);
+					outp = outp + emission;
+					if (exit) {
+						finish = true;
+						filter = false; // mis.rs:29-31 returns before the filter
+					} else {
+						depth = 1;
+						primary = false;
+						if (!(depth < P.max_depth))
+							finish = true;
+					}
+				} else {
+					// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
+					const V3 m_wi = ray.d;
+					const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi);
+					const V3 le = mat_get_emission<F>(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
+					thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi);
+					if (!is_zero(le)) {
+						const bool on_light = F::lights && (prim != kNoPrim) && lights_contain(S, prim) && !mat_is_delta<F>(S, mat);
+						if (on_light || (prim == kNoPrim && sky_samplable)) {
+							// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
+							const uint32_t n_l = F::lights ? S.n_lights : 0u;
+							const float divisor = (float)(sky_samplable ? n_l + 1u : n_l);
+							float l_pdf;
+							if (prim == kNoPrim) {
+								l_pdf = sky_pdf(S, T, m_wi) / divisor;
+							} else {
+								const PrimGeom g = load_prim<F>(S, prim);
+								l_pdf = prim_scattering_pdf<F>(g, hit.point, m_wi, nh) / divisor;
+							}
+							const float mis_weight = power_heuristic(m_pdf, l_pdf);
+							outp = outp + thr * le * mis_weight;
+						} else {
+							outp = outp + thr * le;
+						}
+					}
+					if (mat_is_light(S, nmat)) {
+						finish = true;
+					} else {
+						if (depth > P.rr_threshold) {
+							const float p = component_max(thr);
+							if (rt_rng_f32(&rng) > p)
+								finish = true;
+							else
+								thr = thr / p;
+						}
+						if (!finish) {
+							wo = m_wi;
+							hit = nh;
+							mat = nmat;
+							depth += 1;
+							if (!(depth < P.max_depth))
+								finish = true;
+						}
+					}
+				}
+				if (finish)
+					finalize(filter);
+				else if (METHOD == 1)
+					st = ST_LIGHT; // the path continues: it now waits for the light phase
+			}
+		} else {
+			// ---- [C] sample_lights  mis.rs:95-157 ----
+			const bool cont = (st == ST_LIGHT);
 			bool have_shadow = false, shadow_is_sky = false;
 			Ray sray;
 			sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
@@ -281,7 +326,7 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 			uint32_t light_prim = kNoPrim;
 			if (cont) {
 				ray_count += 1; // mis.rs:38
-				const uint32_t samplable_len = S.n_lights;
+				const uint32_t samplable_len = F::lights ? S.n_lights : 0u;
 				bool pick_sky = false, pick_light = false;
 				uint32_t light_slot = 0;
 				if (samplable_len == 0u) {
@@ -301,17 +346,17 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 				const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
 				if (pick_sky) {
 					l_wi = sky_sample(S, T, rng);
-					sray = ray_new(shadow_origin, l_wi);
+					sray = ray_new<F>(shadow_origin, l_wi);
 					t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
 					have_shadow = true;
 					shadow_is_sky = true;
 				} else if (pick_light) {
 					light_prim = S.lights[light_slot];
-					const PrimGeom g = load_prim(S, light_prim);
-					l_wi = prim_sample_visible_from_point(g, hit.point, rng);
-					sray = ray_new(shadow_origin, l_wi);
+					const PrimGeom g = load_prim<F>(S, light_prim);
+					l_wi = prim_sample_visible_from_point<F>(g, hit.point, rng);
+					sray = ray_new<F>(shadow_origin, l_wi);
 					float lt;
-					if (prim_t(g, sray, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
+					if (prim_t<F>(g, sray, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
 						t_limit = lt;
 						have_shadow = true;
 					}
@@ -319,58 +364,39 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 			}
 			bool occluded = false;
 			if (have_shadow)
-				occluded = trace_any<PRUNE>(S, sray, stk, t_limit, light_prim);
+				occluded = trace_any<F, PRUNE>(S, sray, stk, t_limit, light_prim);
 			if (cont) {
 				if (have_shadow && !occluded) {
 					bool valid = false;
 					V3 le = v3s(0.0f);
 					float l_pdf = 0.0f;
 					if (shadow_is_sky) { // sample_sky  mis.rs:104-115
-						le = mat_get_emission(S, S.sky.material, hit, l_wi);
+						le = mat_get_emission<F>(S, S.sky.material, hit, l_wi);
 						l_pdf = sky_pdf(S, T, l_wi) * pdf_multiplier;
 						valid = true;
 					} else { // sample_light  mis.rs:117-133
 						Hit lh;
 						uint32_t lm;
-						make_hit(S, light_prim, sray, lh, lm);
-						const PrimGeom g = load_prim(S, light_prim);
-						const float p = prim_scattering_pdf(g, hit.point, l_wi, lh);
+						make_hit<F>(S, light_prim, sray, t_limit, lh, lm);
+						const PrimGeom g = load_prim<F>(S, light_prim);
+						const float p = prim_scattering_pdf<F>(g, hit.point, l_wi, lh);
 						if (p > 0.0f) {
-							le = mat_get_emission(S, lm, lh, l_wi);
+							le = mat_get_emission<F>(S, lm, lh, l_wi);
 							l_pdf = p * pdf_multiplier;
 							valid = true;
 						}
 					}
 					if (valid) { // mis.rs:39-43
-						const float m_pdf = mat_scattering_pdf(S, mat, hit, wo, l_wi);
+						const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, l_wi);
 						const float mis_weight = power_heuristic(l_pdf, m_pdf);
-						outp = outp + thr * mat_eval(S, mat, hit, wo, l_wi) * mis_weight * le / l_pdf;
+						outp = outp + thr * mat_eval<F>(S, mat, hit, wo, l_wi) * mis_weight * le / l_pdf;
 					}
 				}
 				// ---- [D] material sampling  mis.rs:46-49 ----
-				if (mat_scatter_ray(S, mat, ray, hit, rng))
-					finish = true;
-			}
-		}
-
-		// ---- sample finished: filter, fold into the running mean, next sample or next pixel ----
-		if (act && finish) {
-			V3 c = outp;
-			if (filter && (contains_nan(c) || !is_finite_any(c)))
-				c = v3s(0.0f);
-			const float i_f = (float)(sample_local + 1u);
-			mean.x += (c.x - mean.x) / i_f; // src/main.rs:179-185
-			mean.y += (c.y - mean.y) / i_f;
-			mean.z += (c.z - mean.z) / i_f;
-			rays_total += ray_count;
-			sample_local += 1;
-			if (sample_local == P.spp) {
-				out[3u * (size_t)out_index + 0u] = mean.x;
-				out[3u * (size_t)out_index + 1u] = mean.y;
-				out[3u * (size_t)out_index + 2u] = mean.z;
-				st = ST_NEED_PIXEL;
-			} else {
-				st = ST_NEW_SAMPLE;
+				if (mat_scatter_ray<F>(S, mat, ray, hit, rng))
+					finalize(true);
+				else
+					st = ST_TRACE;
 			}
 		}
 	}
@@ -414,21 +440,22 @@ template <bool PRUNE>
 __global__ __launch_bounds__(256) void check_hit_kernel(const DevScene S, const DevRayDesc *__restrict__ rays, uint64_t n,
                                                         DevHitRecord *__restrict__ outr)
 {
+	using F = FeatFull; // batch queries serve every scene: all primitive types compiled in
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
-	const Ray r = ray_new(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
+	const Ray r = ray_new<F>(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
 	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
 	float t;
 	uint32_t prim;
-	trace_closest<PRUNE>(S, r, stk, t, prim);
+	trace_closest<F, PRUNE>(S, r, stk, t, prim);
 	Hit h;
 	uint32_t m;
 	if (prim != kNoPrim) {
-		make_hit(S, prim, r, h, m);
+		make_hit<F>(S, prim, r, t, h, m);
 		store_record(outr[i], h, m, prim, true);
 	} else {
 		make_sky_hit(S, h, m);
@@ -441,16 +468,17 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
                                                               const unsigned long long *__restrict__ object_index, uint64_t n,
                                                               DevHitRecord *__restrict__ outr)
 {
+	using F = FeatFull; // batch queries serve every scene: all primitive types compiled in
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
-	const Ray r = ray_new(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
+	const Ray r = ray_new<F>(v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]),
 	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
 	const uint32_t index = (uint32_t)object_index[i];
-	const PrimGeom g = load_prim(S, index);
+	const PrimGeom g = load_prim<F>(S, index);
 	Hit h;
 	h.t = 0.0f;
 	h.point = h.error = h.normal = v3s(0.0f);
@@ -459,9 +487,9 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 	uint32_t m = 0;
 	bool found = false;
 	float lt;
-	if (prim_t(g, r, lt) && lt > 0.0f) {
-		if (!trace_any<PRUNE>(S, r, stk, lt, index)) {
-			make_hit(S, index, r, h, m);
+	if (prim_t<F>(g, r, lt) && lt > 0.0f) {
+		if (!trace_any<F, PRUNE>(S, r, stk, lt, index)) {
+			make_hit<F>(S, index, r, lt, h, m);
 			found = true;
 		}
 	}
@@ -482,15 +510,17 @@ size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_bloc
 
 typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams, float *, unsigned long long *, uint32_t *);
 
-static render_fn pick_render(int method, bool prune, bool sky_lds)
+// feature sets the render kernel is instantiated for (rt_api.cpp picks the smallest that covers the scene)
+using FeatSpheres = Feat<false, false, false, false>; // spheres, Lambertian/Emit, Solid/Lerp, sky is the only light (rtweekend1)
+using FeatSimple = Feat<true, true, false, false>;    // + triangles and emissive primitives (overshadowed, the synthetic meshes)
+
+template <class F> static render_fn pick_render_f(int method, bool prune, bool sky_lds)
 {
 #define RT_PICK(M, P, L) \
 	if (method == M && prune == P && sky_lds == L) \
-		return render_kernel<M, P, L>;
+		return render_kernel<M, P, L, F>;
 	RT_PICK(0, false, false)
-	RT_PICK(0, false, true)
 	RT_PICK(0, true, false)
-	RT_PICK(0, true, true)
 	RT_PICK(1, false, false)
 	RT_PICK(1, false, true)
 	RT_PICK(1, true, false)
@@ -499,20 +529,34 @@ static render_fn pick_render(int method, bool prune, bool sky_lds)
 	return nullptr;
 }
 
-hipError_t render_occupancy(int method, bool prune, bool sky_lds, size_t lds_bytes, int *blocks_per_cu)
+// feature_set: 0 spheres-only, 1 simple, 2 full
+static render_fn pick_render(int method, bool prune, bool sky_lds, int feature_set)
 {
-	render_fn fn = pick_render(method, prune, sky_lds);
+	if (method == 0)
+		sky_lds = false; // the naive integrator never touches the sky tables
+	if (feature_set == 0)
+		return pick_render_f<FeatSpheres>(method, prune, sky_lds);
+	if (feature_set == 1)
+		return pick_render_f<FeatSimple>(method, prune, sky_lds);
+	return pick_render_f<FeatFull>(method, prune, sky_lds);
+}
+
+hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu)
+{
+	render_fn fn = pick_render(method, prune, sky_lds, feature_set);
+	if (!fn)
+		return hipErrorInvalidValue;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess)
 		return e;
 	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 256, lds_bytes);
 }
 
-hipError_t launch_render(int method, bool prune, bool sky_lds, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter)
 {
-	render_fn fn = pick_render(method, prune, sky_lds);
+	render_fn fn = pick_render(method, prune, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
 	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(256), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);

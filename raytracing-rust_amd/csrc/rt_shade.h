@@ -126,7 +126,7 @@ __device__ inline float perlin_noise(const DevTexture &t, V3 point) // :110-169
 	return value;
 }
 
-__device__ __forceinline__ V3 texture_colour(const DevScene &S, uint32_t tex, V3 direction, V3 point)
+template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &S, uint32_t tex, V3 direction, V3 point)
 {
 	const DevTexture &t = S.textures[tex];
 	const int type = t.type;
@@ -136,6 +136,8 @@ __device__ __forceinline__ V3 texture_colour(const DevScene &S, uint32_t tex, V3
 		const float tt = direction.z * 0.5f + 0.5f;
 		return v3(t.c1[0], t.c1[1], t.c1[2]) * tt + v3(t.c2[0], t.c2[1], t.c2[2]) * (1.0f - tt);
 	}
+	if (!F::ctex)
+		return v3s(1.0f); // unreachable: the host launches a ctex variant when such textures exist
 	if (type == 0) { // CheckeredTexture :61-73
 		const float sign = rt_sinf(10.0f * point.x) * rt_sinf(10.0f * point.y) * rt_sinf(10.0f * point.z);
 		return sign > 0.0f ? v3(t.c1[0], t.c1[1], t.c1[2]) : v3(t.c2[0], t.c2[1], t.c2[2]);
@@ -306,48 +308,52 @@ __device__ inline float tr_pdf(float alpha, V3 incoming, V3 outgoing, V3 normal)
 
 // ---- materials ----
 __device__ __forceinline__ V3 fresnel(float c, V3 f0) { return f0 + (1.0f - f0) * rt_pow5f(1.0f - c); } // refract.rs:59-61
-__device__ inline V3 tr_fresnel(const DevScene &S, const DevMaterial &m, const Hit &hit, V3 wo, V3 wi, V3 h) // trowbridge_reitz.rs:26-31
+template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevMaterial &m, const Hit &hit, V3 wo, V3 wi, V3 h) // trowbridge_reitz.rs:26-31
 {
 	const V3 ior = v3(m.ior[0], m.ior[1], m.ior[2]);
 	V3 f0 = vabs((1.0f - ior) / (1.0f + ior));
 	f0 = f0 * f0;
-	const V3 tex = texture_colour(S, m.texture, wi, hit.point);
+	const V3 tex = texture_colour<F>(S, m.texture, wi, hit.point);
 	f0 = (1.0f - m.metallic) * f0 + m.metallic * tex; // lerp :89-91
 	return fresnel(dot(wo, h), f0);
 }
 
 __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return S.materials[mat].type == 0; }
-__device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
+template <class F> __device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
 {
+	if (!F::cmat)
+		return false;
 	const int t = S.materials[mat].type;
 	return t == 3 || t == 4;
 }
 
-__device__ __forceinline__ bool reflect_scatter(float fuzz, Ray &ray, const Hit &hit, rt_rng &rng) // reflect.rs:25-35
+template <class F> __device__ __forceinline__ bool reflect_scatter(float fuzz, Ray &ray, const Hit &hit, rt_rng &rng) // reflect.rs:25-35
 {
 	V3 direction = -ray.d;
 	direction = reflected(direction, hit.normal);
 	const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
 	const V3 ruv = random_unit_vector(rng);
-	ray = ray_new(point, direction + fuzz * ruv);
+	ray = ray_new<F>(point, direction + fuzz * ruv);
 	return false;
 }
 
 // Scatter::scatter_ray; returns `exit`
-__device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng)
+template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng)
 {
 	const DevMaterial &m = S.materials[mat];
 	const int type = m.type;
 	if (type == 1) { // Lambertian  lambertian.rs:30-41
 		const V3 direction = lambertian_sample(hit.normal, rng);
 		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
-		ray = ray_new(point, direction);
+		ray = ray_new<F>(point, direction);
 		return false;
 	}
 	if (type == 0) // Emit  emissive.rs:36-38
 		return true;
+	if (!F::cmat)
+		return true; // unreachable: a cmat variant is launched when such materials exist
 	if (type == 3) // Reflect
-		return reflect_scatter(m.param, ray, hit, rng);
+		return reflect_scatter<F>(m.param, ray, hit, rng);
 	if (type == 4) { // Refract  refract.rs:26-50
 		const float eta = m.param;
 		float eta_fraction = 1.0f / eta;
@@ -359,47 +365,49 @@ __device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat,
 		const float f0s = (1.0f - eta_fraction) / (1.0f + eta_fraction);
 		const V3 f0 = (f0s * f0s) * v3s(1.0f);
 		if (cannot_refract || fresnel(cos_theta, f0).x > rt_rng_f32(&rng))
-			return reflect_scatter(0.0f, ray, hit, rng);
+			return reflect_scatter<F>(0.0f, ray, hit, rng);
 		const V3 perp = eta_fraction * (ray.d + cos_theta * hit.normal);
 		const V3 para = (-1.0f * sqrtf(fabsf(1.0f - mag_sq(perp)))) * hit.normal;
 		const V3 point = offset_ray(hit.point, hit.normal, hit.error, false);
-		ray = ray_new(point, perp + para);
+		ray = ray_new<F>(point, perp + para);
 		return false;
 	}
 	if (type == 2) { // TrowbridgeReitz  trowbridge_reitz.rs:38-51
 		const V3 direction = tr_sample(m.param, -ray.d, hit.normal, rng);
 		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
-		ray = ray_new(point, direction);
+		ray = ray_new<F>(point, direction);
 		return false;
 	}
 	return true;
 }
 
-__device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
 		return fmax_(dot(wi, hit.normal), 0.0f) / kPi;
-	if (m.type == 2) { // trowbridge_reitz.rs:52-60
+	if (F::cmat && m.type == 2) { // trowbridge_reitz.rs:52-60
 		const float a = tr_pdf(m.param, -wo, wi, hit.normal);
 		return a == 0.0f ? INFINITY : a;
 	}
 	return 0.0f; // trait default (Reflect, Refract)
 }
 
-__device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 1) // lambertian.rs:45-47
-		return texture_colour(S, m.texture, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+		return texture_colour<F>(S, m.texture, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+	if (!F::cmat)
+		return v3s(0.0f);
 	if (m.type == 3 || m.type == 4) // reflect.rs:36-38, refract.rs:51-53
-		return texture_colour(S, m.texture, wo, hit.point);
+		return texture_colour<F>(S, m.texture, wo, hit.point);
 	if (m.type == 2) { // trowbridge_reitz.rs:61-74
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
 		if (dot(wi, hit.normal) < 0.0f || dot(h, wom) < 0.0f)
 			return v3s(0.0f);
-		const V3 f = tr_fresnel(S, m, hit, wom, wi, h);
+		const V3 f = tr_fresnel<F>(S, m, hit, wom, wi, h);
 		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
 		const float d = tr_d(m.param, dot(hit.normal, h));
 		return f * g * d / (4.0f * fabsf(dot(wom, hit.normal)) * dot(wi, hit.normal));
@@ -407,45 +415,47 @@ __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hi
 	return v3s(0.0f); // Emit::eval is unreachable!() in the reference
 }
 
-__device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 1) // lambertian.rs:48-50
-		return texture_colour(S, m.texture, wo, hit.point) * m.param;
+		return texture_colour<F>(S, m.texture, wo, hit.point) * m.param;
+	if (!F::cmat)
+		return v3s(0.0f); // unreachable without Reflect/Refract/TrowbridgeReitz
 	if (m.type == 2) { // trowbridge_reitz.rs:75-87
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
 		if (dot(wom, h) < 0.0f || dot(wi, hit.normal) < 0.0f)
 			return v3s(0.0f);
-		const V3 f = tr_fresnel(S, m, hit, wom, wi, h);
+		const V3 f = tr_fresnel<F>(S, m, hit, wom, wi, h);
 		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
 		return f * g / tr_g1(m.param, hit.normal, h, wom);
 	}
 	// trait default: eval / scattering_pdf  (rt_core/src/material.rs:24-26)
-	return mat_eval(S, mat, hit, wo, wi) / mat_scattering_pdf(S, mat, hit, wo, wi);
+	return mat_eval<F>(S, mat, hit, wo, wi) / mat_scattering_pdf<F>(S, mat, hit, wo, wi);
 }
 
-__device__ __forceinline__ V3 mat_get_emission(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo)
+template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo)
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 0) { // emissive.rs:23-26
 		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
-		return m.param * texture_colour(S, m.texture, wo, point);
+		return m.param * texture_colour<F>(S, m.texture, wo, point);
 	}
 	return v3s(0.0f);
 }
 
 // ---- light-sampling geometry of primitives ----
-__device__ __forceinline__ float prim_area(const PrimGeom &g) // sphere.rs:167-169, triangle.rs:226-230
+template <class F> __device__ __forceinline__ float prim_area(const PrimGeom &g) // sphere.rs:167-169, triangle.rs:226-230
 {
-	if (g.type == kPrimSphere)
+	if (!F::tri || g.type == kPrimSphere)
 		return 4.0f * kPi * g.p1.x * g.p1.x;
 	return 0.5f * mag(cross(g.p1 - g.p0, g.p2 - g.p0));
 }
 // sample_visible_from_point  sphere.rs:118-154, triangle.rs:231-241,263-277
-__device__ inline V3 prim_sample_visible_from_point(const PrimGeom &g, V3 in_point, rt_rng &rng)
+template <class F> __device__ inline V3 prim_sample_visible_from_point(const PrimGeom &g, V3 in_point, rt_rng &rng)
 {
-	if (g.type == kPrimSphere) {
+	if (!F::tri || g.type == kPrimSphere) {
 		const V3 center = g.p0;
 		const float radius = g.p1.x;
 		const float distance_sq = mag_sq(in_point - center);
@@ -482,18 +492,18 @@ __device__ inline V3 prim_sample_visible_from_point(const PrimGeom &g, V3 in_poi
 	return normalised(point - in_point);
 }
 // Primitive::scattering_pdf  sphere.rs:155-166, triangle.rs:242-244,278-280
-__device__ __forceinline__ float prim_scattering_pdf(const PrimGeom &g, V3 hit_point, V3 wi, const Hit &sampled_hit)
+template <class F> __device__ __forceinline__ float prim_scattering_pdf(const PrimGeom &g, V3 hit_point, V3 wi, const Hit &sampled_hit)
 {
-	if (g.type == kPrimSphere) {
+	if (!F::tri || g.type == kPrimSphere) {
 		const float rsq = g.p1.x * g.p1.x;
 		const float dsq = mag_sq(hit_point - g.p0);
 		if (dsq <= rsq)
-			return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(wi, sampled_hit.normal)) * prim_area(g));
+			return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(wi, sampled_hit.normal)) * prim_area<F>(g));
 		const float sin_theta_max_sq = rsq / dsq;
 		const float cos_theta_max = sqrtf(fmax_(1.0f - sin_theta_max_sq, 0.0f));
 		return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));
 	}
-	return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(sampled_hit.normal, wi)) * prim_area(g));
+	return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(sampled_hit.normal, wi)) * prim_area<F>(g));
 }
 
 } // namespace rt

@@ -21,6 +21,18 @@ namespace rt {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu; // usize::MAX on the device side
 
+// Compile-time description of what a scene can contain.  The kernels are instantiated for a few
+// feature sets and rt_api.cpp launches the smallest one that covers the scene: code for absent
+// primitive / material / texture types is not even compiled in (smaller kernel, fewer registers).
+// The arithmetic of what IS present is untouched, so every variant returns the same pixels.
+template <bool TRI, bool LIGHTS, bool CMAT, bool CTEX> struct Feat {
+	static constexpr bool tri = TRI;       // Triangle / MeshTriangle primitives
+	static constexpr bool lights = LIGHTS; // emissive primitives (Bvh.lights non-empty)
+	static constexpr bool cmat = CMAT;     // Reflect / Refract / TrowbridgeReitz materials
+	static constexpr bool ctex = CTEX;     // Checkered / Image / Perlin textures
+};
+using FeatFull = Feat<true, true, true, true>;
+
 // child reference: >= 0 inner node index; < 0 leaf whose first primitive slot is ~ref
 struct alignas(64) DevNode {
 	float c0min[3], c0max[3];
