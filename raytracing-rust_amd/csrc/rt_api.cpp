@@ -182,6 +182,11 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.prim_rank.data(), h.prim_rank.size(), &D.prim_rank)) != RT_OK) return bail(rc);
+	{
+		const uint32_t *d_big = nullptr;
+		if ((rc = upload(s, h.big_leaves.data(), h.big_leaves.size(), &d_big)) != RT_OK) return bail(rc);
+		D.big_leaves = reinterpret_cast<const uint2 *>(d_big);
+	}
 	if ((rc = upload(s, h.materials.data(), h.materials.size(), &D.materials)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.textures.data(), h.textures.size(), &D.textures)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
@@ -193,7 +198,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	D.n_lights = (uint32_t)h.dev_lights.size();
 	D.n_materials = (uint32_t)h.materials.size();
 	D.n_textures = (uint32_t)h.textures.size();
-	D.root_is_leaf = h.root_is_leaf ? 1 : 0;
+	D.root_ref = h.root_ref;
 	std::memcpy(D.root_min, h.root_min, sizeof D.root_min);
 	std::memcpy(D.root_max, h.root_max, sizeof D.root_max);
 	D.stack_depth = h.stack_depth;

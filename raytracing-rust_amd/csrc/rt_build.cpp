@@ -481,16 +481,28 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 	const HostNode &root = hs.nodes[0];
 	std::memcpy(hs.root_min, root.min, sizeof hs.root_min);
 	std::memcpy(hs.root_max, root.max, sizeof hs.root_max);
-	hs.root_is_leaf = root.child[0] < 0;
 	hs.dev_nodes.clear();
+	hs.big_leaves.clear();
+	if (n > kLeafSlotMask) {
+		err = "more than 2^26 primitives: leaf references hold 26-bit slots";
+		return RT_ERR_UNSUPPORTED;
+	}
+	auto leaf_ref = [&](const HostNode &leaf) -> uint32_t {
+		if (leaf.number_primitives <= kLeafInlineMax)
+			return kLeafFlag | ((uint32_t)leaf.number_primitives << 26) | (uint32_t)leaf.primitive_offset;
+		hs.big_leaves.push_back((uint32_t)leaf.primitive_offset);
+		hs.big_leaves.push_back((uint32_t)leaf.number_primitives);
+		return kLeafFlag | (uint32_t)(hs.big_leaves.size() / 2 - 1);
+	};
 	uint32_t max_depth = 1;
-	if (!hs.root_is_leaf) {
+	if (root.child[0] >= 0) {
 		std::vector<int64_t> dev_index(hs.nodes.size(), -1);
 		uint32_t n_inner = 0;
 		for (size_t i = 0; i < hs.nodes.size(); ++i) // host order is already preorder
 			if (hs.nodes[i].child[0] >= 0)
 				dev_index[i] = n_inner++;
 		hs.dev_nodes.resize(n_inner);
+		hs.root_ref = 0;
 		// depth of the inner-node tree (stack entries needed by the depth-first walk)
 		std::vector<std::pair<uint64_t, uint32_t>> work;
 		work.push_back({0, 1});
@@ -500,32 +512,26 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			const HostNode &hn = hs.nodes[id];
 			max_depth = std::max(max_depth, depth);
 			DevNode &dn = hs.dev_nodes[(size_t)dev_index[id]];
+			dn.pad0 = dn.pad1 = 0;
 			for (int c = 0; c < 2; ++c) {
 				const HostNode &ch = hs.nodes[(size_t)hn.child[c]];
 				float *mn = c == 0 ? dn.c0min : dn.c1min, *mx = c == 0 ? dn.c0max : dn.c1max;
 				std::memcpy(mn, ch.min, 12);
 				std::memcpy(mx, ch.max, 12);
-				int32_t ref;
-				uint32_t cnt = 0;
+				uint32_t ref;
 				if (ch.child[0] >= 0) {
-					ref = (int32_t)dev_index[(size_t)hn.child[c]];
+					ref = (uint32_t)dev_index[(size_t)hn.child[c]];
 					work.push_back({(uint64_t)hn.child[c], depth + 1});
 				} else {
-					ref = (int32_t)~(uint32_t)ch.primitive_offset;
-					cnt = (uint32_t)ch.number_primitives;
+					ref = leaf_ref(ch);
 				}
-				if (c == 0) {
-					dn.c0 = ref;
-					dn.n0 = cnt;
-				} else {
-					dn.c1 = ref;
-					dn.n1 = cnt;
-				}
+				(c == 0 ? dn.c0 : dn.c1) = ref;
 			}
 		}
 	} else {
 		hs.dev_nodes.resize(1);
 		std::memset(hs.dev_nodes.data(), 0, sizeof(DevNode));
+		hs.root_ref = leaf_ref(root);
 	}
 	hs.stack_depth = max_depth + 1;
 	if (hs.stack_depth > 96) {

@@ -27,6 +27,8 @@ struct HostScene {
 	std::vector<DevPrim> dev_prims;
 	std::vector<DevShade> dev_shade;
 	std::vector<uint32_t> prim_rank;
+	std::vector<uint32_t> big_leaves; // pairs (first slot, count)
+	uint32_t root_ref = 0;
 	std::vector<uint32_t> dev_lights;
 	std::vector<DevMaterial> materials;
 	std::vector<DevTexture> textures;            // image / perlin pointers are patched after upload
@@ -35,7 +37,6 @@ struct HostScene {
 	std::vector<std::vector<uint32_t>> tex_perlin_perm;
 	std::vector<float> sky_cdf;                  // rows (res_y * (res_x+1)) then marginal (res_y+1)
 	rt_sky_desc sky;
-	bool root_is_leaf = false;
 	float root_min[3], root_max[3];
 	uint32_t stack_depth = 2;
 	bool has_triangles = false;

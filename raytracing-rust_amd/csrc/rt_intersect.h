@@ -273,9 +273,18 @@ __device__ __forceinline__ void make_sky_hit(const DevScene &S, Hit &h, uint32_t
 }
 
 // ---- traversal ----
+// "while-while" walk (Aila & Laine, HPG 2009) for 64-lane wavefronts.  A lane descends through
+// INNER nodes until the next thing it has to look at is a LEAF; only then does it fall out of the
+// inner loop.  The wave reconverges there, so the (long) primitive intersection code runs with
+// most lanes holding a leaf, instead of once per iteration for the one or two lanes that happen
+// to be at a leaf.  Leaf references are ordinary 32-bit stack entries:
+//   ref >= 0                inner node index
+//   ref <  0 (bit 31 set)   leaf: bits 26-30 primitive count (1..31), bits 0-25 first slot;
+//                           count field 0 = index into DevScene::big_leaves (first, count)
 // Per-lane stack in LDS: entry e of lane l lives at stack[e * 64 + l]; `stk` already points at
 // the lane's column, so consecutive lanes hit consecutive banks (conflict-free ds_read/ds_write_b32).
 constexpr int kStackStride = 64;
+constexpr uint32_t kRefDone = 0x7FFFFFFFu; // sentinel: traversal finished
 // Slack used by the pruned walk: a child whose entry distance exceeds the current best t by more
 // than this cannot contain a primitive that beats or ties it (the slab test and the intersectors
 // agree to a few ulp; 3e-5 relative is ~250 ulp).  The exhaustive walk (prune = false) needs none.
@@ -283,8 +292,7 @@ constexpr float kPruneSlack = 3.0e-5f;
 
 struct NodeView {
 	float c0min[3], c0max[3], c1min[3], c1max[3];
-	int32_t c0, c1;
-	uint32_t n0, n1;
+	uint32_t c0, c1;
 };
 __device__ __forceinline__ NodeView load_node(const DevScene &S, uint32_t node)
 {
@@ -295,42 +303,69 @@ __device__ __forceinline__ NodeView load_node(const DevScene &S, uint32_t node)
 	n.c0max[0] = q0.w; n.c0max[1] = q1.x; n.c0max[2] = q1.y;
 	n.c1min[0] = q1.z; n.c1min[1] = q1.w; n.c1min[2] = q2.x;
 	n.c1max[0] = q2.y; n.c1max[1] = q2.z; n.c1max[2] = q2.w;
-	n.c0 = (int32_t)__float_as_uint(q3.x);
-	n.c1 = (int32_t)__float_as_uint(q3.y);
-	n.n0 = __float_as_uint(q3.z);
-	n.n1 = __float_as_uint(q3.w);
+	n.c0 = __float_as_uint(q3.x);
+	n.c1 = __float_as_uint(q3.y);
 	return n;
 }
 __device__ __forceinline__ float box_extent_l1(const float mn[3], const float mx[3])
 {
 	return (mx[0] - mn[0]) + (mx[1] - mn[1]) + (mx[2] - mn[2]);
 }
-
-// Bvh::check_hit's selection rule over a leaf  mod.rs:270-293
-template <class F> __device__ __forceinline__ void closest_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float &best_t,
-                                             uint32_t &best_prim)
+__device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & 0x80000000u) != 0u; }
+__device__ __forceinline__ void leaf_range(const DevScene &S, uint32_t ref, uint32_t &first, uint32_t &count)
 {
-	for (uint32_t slot = first; slot < first + count; ++slot) {
-		const PrimGeom g = load_prim<F>(S, slot);
-		float t;
-		if (prim_t<F>(g, r, t) && t > 0.0f) {
-			bool take;
-			if (best_prim == kNoPrim)
-				take = true;
-			else if (t < best_t)
-				take = true;
-			else if (t == best_t)
-				take = S.prim_rank[slot] < S.prim_rank[best_prim]; // reference order: first in BFS-leaf order wins
-			else
-				take = false;
-			if (take) {
-				best_t = t;
-				best_prim = slot;
-			}
-		}
+	count = (ref >> 26) & 31u;
+	first = ref & 0x03FFFFFFu;
+	if (count == 0u) { // a leaf of 32+ primitives (coincident centroids, acceleration/mod.rs:129-134)
+		const uint2 e = S.big_leaves[first];
+		first = e.x;
+		count = e.y;
 	}
 }
+// can a box entered at distance t_entry still hold a primitive that beats or ties t_best?
+__device__ __forceinline__ bool beyond(float t_entry, float t_best, const float mn[3], const float mx[3])
+{
+	return t_entry - kPruneSlack * (fabsf(t_entry) + fabsf(t_best) + box_extent_l1(mn, mx)) > t_best;
+}
 
+// One step of the inner-node descent shared by both walks: fetch `node`, test both child boxes
+// with the reference's predicate, choose where to go next.  limit_valid/t_limit: prune children
+// entered beyond t_limit (PRUNE only).
+template <bool PRUNE>
+__device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid,
+                                            float t_limit)
+{
+	const NodeView n = load_node(S, node);
+	float t0, t1;
+	bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+	bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+	if (PRUNE && limit_valid) {
+		if (h0 && beyond(t0, t_limit, n.c0min, n.c0max))
+			h0 = false;
+		if (h1 && beyond(t1, t_limit, n.c1min, n.c1max))
+			h1 = false;
+	}
+	if (h0 && h1) {
+		uint32_t near = n.c0, far = n.c1;
+		if (PRUNE && t1 < t0) { // nearer child first, so the farther one can be pruned later
+			near = n.c1;
+			far = n.c0;
+		}
+		stk[sp * kStackStride] = far;
+		++sp;
+		return near;
+	}
+	if (h0)
+		return n.c0;
+	if (h1)
+		return n.c1;
+	if (sp == 0)
+		return kRefDone;
+	--sp;
+	return stk[sp * kStackStride];
+}
+
+// Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
 template <class F, bool PRUNE>
 __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
 {
@@ -339,60 +374,38 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 	float tm;
 	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
 		return;
-	if (S.root_is_leaf) {
-		closest_leaf<F>(S, r, 0, S.n_prims, best_t, best_prim);
-		return;
-	}
 	int sp = 0;
-	uint32_t node = 0;
-	for (;;) {
-		const NodeView n = load_node(S, node);
-		float t0, t1;
-		bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
-		bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
-		if (PRUNE) {
-			if (h0 && h1 && t1 < t0 && n.c0 < 0 && n.c1 < 0) {
-				// two leaves: test the nearer first so the farther may be pruned
-				if (!(best_prim != kNoPrim && t1 - kPruneSlack * (fabsf(t1) + fabsf(best_t) + box_extent_l1(n.c1min, n.c1max)) > best_t))
-					closest_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
-				h1 = false;
+	uint32_t node = S.root_ref;
+	while (node != kRefDone) {
+		while (!ref_is_leaf(node) && node != kRefDone)
+			node = descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
+		if (node == kRefDone)
+			break;
+		uint32_t first, count;
+		leaf_range(S, node, first, count);
+		for (uint32_t slot = first; slot < first + count; ++slot) { // selection rule of mod.rs:270-293
+			const PrimGeom g = load_prim<F>(S, slot);
+			float t;
+			if (prim_t<F>(g, r, t) && t > 0.0f) {
+				bool take;
+				if (best_prim == kNoPrim)
+					take = true;
+				else if (t < best_t)
+					take = true;
+				else if (t == best_t)
+					take = S.prim_rank[slot] < S.prim_rank[best_prim]; // reference order: first in BFS-leaf order wins
+				else
+					take = false;
+				if (take) {
+					best_t = t;
+					best_prim = slot;
+				}
 			}
-			if (h0 && best_prim != kNoPrim &&
-			    t0 - kPruneSlack * (fabsf(t0) + fabsf(best_t) + box_extent_l1(n.c0min, n.c0max)) > best_t)
-				h0 = false;
 		}
-		if (h0 && n.c0 < 0) {
-			closest_leaf<F>(S, r, (uint32_t)~n.c0, n.n0, best_t, best_prim);
-			h0 = false;
-		}
-		if (PRUNE) {
-			if (h1 && best_prim != kNoPrim &&
-			    t1 - kPruneSlack * (fabsf(t1) + fabsf(best_t) + box_extent_l1(n.c1min, n.c1max)) > best_t)
-				h1 = false;
-		}
-		if (h1 && n.c1 < 0) {
-			closest_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, best_t, best_prim);
-			h1 = false;
-		}
-		if (h0 && h1) {
-			uint32_t near = (uint32_t)n.c0, far = (uint32_t)n.c1;
-			if (PRUNE && t1 < t0) {
-				near = (uint32_t)n.c1;
-				far = (uint32_t)n.c0;
-			}
-			stk[sp * kStackStride] = far;
-			++sp;
-			node = near;
-		} else if (h0) {
-			node = (uint32_t)n.c0;
-		} else if (h1) {
-			node = (uint32_t)n.c1;
-		} else {
-			if (sp == 0)
-				break;
-			--sp;
-			node = stk[sp * kStackStride];
-		}
+		if (sp == 0)
+			break;
+		--sp;
+		node = stk[sp * kStackStride];
 	}
 }
 
@@ -400,65 +413,36 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 // returning an index != usize::MAX, mis.rs:104-115) and Bvh::check_hit_index (mod.rs:244-261):
 // some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
 // limit" (any t > 0 occludes).
-template <class F> __device__ __forceinline__ bool any_leaf(const DevScene &S, const Ray &r, uint32_t first, uint32_t count, float t_limit, uint32_t skip)
-{
-	for (uint32_t slot = first; slot < first + count; ++slot) {
-		if (slot == skip)
-			continue;
-		const PrimGeom g = load_prim<F>(S, slot);
-		float t;
-		if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
-			return true;
-	}
-	return false;
-}
-
 template <class F, bool PRUNE>
 __device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
 {
 	float tm;
 	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
 		return false;
-	if (S.root_is_leaf)
-		return any_leaf<F>(S, r, 0, S.n_prims, t_limit, skip);
+	const bool limited = !(t_limit != t_limit);
 	int sp = 0;
-	uint32_t node = 0;
-	for (;;) {
-		const NodeView n = load_node(S, node);
-		float t0, t1;
-		bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
-		bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
-		if (PRUNE) { // t_limit NaN: comparisons are false, nothing is pruned
-			if (h0 && t0 - kPruneSlack * (fabsf(t0) + fabsf(t_limit) + box_extent_l1(n.c0min, n.c0max)) > t_limit)
-				h0 = false;
-			if (h1 && t1 - kPruneSlack * (fabsf(t1) + fabsf(t_limit) + box_extent_l1(n.c1min, n.c1max)) > t_limit)
-				h1 = false;
-		}
-		if (h0 && n.c0 < 0) {
-			if (any_leaf<F>(S, r, (uint32_t)~n.c0, n.n0, t_limit, skip))
+	uint32_t node = S.root_ref;
+	while (node != kRefDone) {
+		while (!ref_is_leaf(node) && node != kRefDone)
+			node = descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
+		if (node == kRefDone)
+			break;
+		uint32_t first, count;
+		leaf_range(S, node, first, count);
+		for (uint32_t slot = first; slot < first + count; ++slot) {
+			if (slot == skip)
+				continue;
+			const PrimGeom g = load_prim<F>(S, slot);
+			float t;
+			if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
 				return true;
-			h0 = false;
 		}
-		if (h1 && n.c1 < 0) {
-			if (any_leaf<F>(S, r, (uint32_t)~n.c1, n.n1, t_limit, skip))
-				return true;
-			h1 = false;
-		}
-		if (h0 && h1) {
-			stk[sp * kStackStride] = (uint32_t)n.c1;
-			++sp;
-			node = (uint32_t)n.c0;
-		} else if (h0) {
-			node = (uint32_t)n.c0;
-		} else if (h1) {
-			node = (uint32_t)n.c1;
-		} else {
-			if (sp == 0)
-				return false;
-			--sp;
-			node = stk[sp * kStackStride];
-		}
+		if (sp == 0)
+			break;
+		--sp;
+		node = stk[sp * kStackStride];
 	}
+	return false;
 }
 
 } // namespace rt

@@ -34,7 +34,7 @@ namespace rt {
 enum : int { ST_NEED_PIXEL = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_LIGHT = 3, ST_DONE = 4 };
 // the LIGHT phase runs once this many lanes of the wave wait for it (or nobody wants the TRACE phase)
 #ifndef RT_LIGHT_PHASE_THRESHOLD
-#define RT_LIGHT_PHASE_THRESHOLD 32
+#define RT_LIGHT_PHASE_THRESHOLD 40
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 
@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 					const V3 le = mat_get_emission<F>(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
 					thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi);
 					if (!is_zero(le)) {
-						const bool on_light = F::lights && (prim != kNoPrim) && lights_contain(S, prim) && !mat_is_delta<F>(S, mat);
+						// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
+						// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
+						const bool on_light = F::lights && (prim != kNoPrim) && mat_is_light(S, nmat) && !mat_is_delta<F>(S, mat);
 						if (on_light || (prim == kNoPrim && sky_samplable)) {
 							// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
 							const uint32_t n_l = F::lights ? S.n_lights : 0u;

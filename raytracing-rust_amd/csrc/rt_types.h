@@ -33,12 +33,16 @@ template <bool TRI, bool LIGHTS, bool CMAT, bool CTEX> struct Feat {
 };
 using FeatFull = Feat<true, true, true, true>;
 
-// child reference: >= 0 inner node index; < 0 leaf whose first primitive slot is ~ref
+// child reference: bit 31 clear = inner node index; bit 31 set = leaf, bits 26-30 primitive count
+// (1..31; 0 = entry of DevScene::big_leaves), bits 0-25 first primitive slot (or big-leaf index)
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kLeafInlineMax = 31u;
+constexpr uint32_t kLeafSlotMask = 0x03FFFFFFu;
 struct alignas(64) DevNode {
 	float c0min[3], c0max[3];
 	float c1min[3], c1max[3];
-	int32_t c0, c1;
-	uint32_t n0, n1; // primitive counts when the child is a leaf
+	uint32_t c0, c1;
+	uint32_t pad0, pad1;
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 
@@ -91,8 +95,9 @@ struct DevScene {
 	const DevMaterial *materials;
 	const DevTexture *textures;
 	const uint32_t *lights;    // Bvh.lights
+	const uint2 *big_leaves;   // (first slot, count) of leaves with more than 31 primitives
 	uint32_t n_nodes, n_prims, n_lights, n_materials, n_textures;
-	int32_t root_is_leaf;      // the whole tree is one leaf node
+	uint32_t root_ref;         // child-style reference to the root (a leaf ref when the tree is one leaf)
 	float root_min[3], root_max[3];
 	uint32_t stack_depth;      // traversal stack entries per lane (tree depth + 1)
 	uint32_t has_triangles;
