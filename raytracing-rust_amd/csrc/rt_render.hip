@@ -10,20 +10,28 @@
 // MI355X design: there are no passes.  A lane OWNS a pixel for all of its samples: it draws the
 // camera ray, walks the path, folds the sample into the pixel's running mean in registers
 // (`mean += (sample - mean) / i`, the reference's own update, in sample order -- so the mean is
-// bit-identical to the reference's accumulation order), and writes the pixel once.  Paths last
-// 1..49 bounces, so lanes of a wavefront finish samples at different times; a finished lane
-// immediately regenerates the next sample (or pulls the next pixel from a global queue with one
-// wave-aggregated atomic: __ballot + popcount + one atomicAdd per wave) instead of idling until
-// the longest path of the wave ends.  A bounce has two halves:
-//   TRACE phase  [A] closest-hit walk of the lane's current ray (camera ray or bounce ray)
-//                [B] shade: emission, MIS weight, Russian roulette, or sample finished
-//   LIGHT phase  [C] light sample (sky table in LDS / light primitive) + any-hit shadow walk
-//                [D] BSDF sample -> next bounce ray
-// About half of all [B] outcomes end the sample (the ray left for the sky), so running A-B-C-D in
-// lockstep leaves those lanes idle through C-D.  Instead every iteration the wave votes
-// (__ballot/popcount) and runs the phase most of its lanes wait for; finished lanes regenerate and
-// stay in the TRACE phase while continuing paths pile up for the LIGHT phase.  Paths never read
-// each other's state and each owns its random stream, so the schedule cannot change a pixel.
+// bit-identical to the reference's accumulation order), and writes the pixel once.
+//
+// Paths last 1..49 bounces, a ray visits 3..500 BVH nodes, about half of all shading events end
+// the sample: 64 lanes in lockstep would mostly wait for each other.  So the kernel is a per-lane
+// state machine whose steps ("phases") are small, and every loop iteration the WAVE votes
+// (__ballot + popcount) and executes the one phase most of its lanes are waiting for; the other
+// lanes keep their state in registers / their traversal stack in LDS and are served by a later
+// iteration:
+//   GEN      new sample: seed the stream, camera ray, start a closest-hit walk
+//   NODE     one inner-node step of a BVH walk (fetch 64-B node, two slab tests, push/pop)
+//   LEAF     intersect the primitives of one leaf
+//   SHADE    closest hit known: emission, MIS weight, Russian roulette, sample finished?   (mis.rs:17-33,50-86)
+//   LIGHT    sample_lights: pick sky / light primitive, build the shadow ray, start an any-hit walk (mis.rs:95-157)
+//   SCATTER  light contribution, BSDF sample -> next ray, start a closest-hit walk          (mis.rs:39-49)
+// For tiny trees (a walk is 1-3 steps) the vote is coarser: TRACE = GEN + walk + SHADE and
+// LIGHT = LIGHT + shadow walk + SCATTER are voted as two super-phases (constexpr FINE below).
+// NODE and LEAF are shared by path rays and shadow rays (a per-lane flag selects closest / any
+// hit), so bounce rays of some lanes and shadow rays of others traverse together.  A lane whose
+// pixel is finished pulls the next one from a global queue with one wave-aggregated atomic.
+// Paths never read each other's state and each owns its random stream (seed, pixel, sample), so
+// the schedule cannot change a pixel: results are bit-identical to the serial reference order.
+//
 // Scene data is read-only and shared: BVH / primitives through L1/L2 from HBM, the sky's CDF rows
 // staged once per workgroup into LDS next to the per-lane traversal stacks.  HBM write traffic is
 // 12 bytes per pixel for the whole render.  No MFMA: nothing here is a dense contraction.
@@ -31,12 +39,26 @@
 
 namespace rt {
 
-enum : int { ST_NEED_PIXEL = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_LIGHT = 3, ST_DONE = 4 };
-// the LIGHT phase runs once this many lanes of the wave wait for it (or nobody wants the TRACE phase)
+enum : int {
+	PH_GEN = 0,
+	PH_NODE = 1,
+	PH_LEAF = 2,
+	PH_SHADE = 3,
+	PH_LIGHT = 4,
+	PH_SCATTER = 5,
+	PH_COUNT = 6,
+	PH_NEED_PIXEL = 6, // served at the top of every iteration (one atomic per wave), not voted
+	PH_DONE = 7
+};
+
+// coarse schedule: the LIGHT super-phase runs once this many lanes of the wave wait for it
 #ifndef RT_LIGHT_PHASE_THRESHOLD
 #define RT_LIGHT_PHASE_THRESHOLD 40
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
+#ifndef RT_SPHERES_WAVES
+#define RT_SPHERES_WAVES 3 // waves per SIMD the spheres-only variants are register-limited to
+#endif
 
 __device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt_core/src/lib.rs:36-40
 {
@@ -47,6 +69,8 @@ __device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt
 // work item -> pixel.  Work items enumerate this shard's tiles (tile t belongs to shard
 // t % shard_count) row-major inside each tile, so the 64 lanes of a wave start on one compact
 // tile_w x tile_h block of the image (coherent primary rays).
+// (Handing tiles out bottom-up, so that the tail of the render is cheap sky pixels, was measured
+// SLOWER on rtweekend1: 181 ms vs 154 ms.  Waves that mix cheap and expensive pixels vote better.)
 __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t w, uint32_t &x, uint32_t &y)
 {
 	const uint32_t tile_pixels = P.tile_w * P.tile_h;
@@ -60,19 +84,14 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 	return x < P.width && y < P.height;
 }
 
-__device__ __forceinline__ bool lights_contain(const DevScene &S, uint32_t prim) // bvh.get_samplable().contains(&index)  mis.rs:58
-{
-	for (uint32_t i = 0; i < S.n_lights; ++i)
-		if (S.lights[i] == prim)
-			return true;
-	return false;
-}
-
 template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
-__global__ __launch_bounds__(256) void render_kernel(const DevScene S, const DevCamera cam, const DevRenderParams P,
+__global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::lights) ? 3 : RT_SPHERES_WAVES)) void render_kernel(const DevScene S, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
 {
+	// Scheduling granularity follows the tree: the pruned walk is selected for scenes with more than
+	// a few dozen primitives, where one walk is tens to hundreds of steps and each step deserves a vote.
+	constexpr bool FINE = PRUNE;
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
@@ -104,11 +123,18 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 	const V3 cam_v = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
 	const bool sky_samplable = sky_can_sample(S);
 
-	// ---- per-lane path state (registers) ----
-	int st = ST_NEED_PIXEL;
+	// ---- per-lane state (registers) ----
+	int ph = PH_NEED_PIXEL;
 	rt_rng rng = {1u, 2u, 3u, 4u};
+	// the walk in progress: its ray, where it stands, what it has found
 	Ray ray;
 	ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
+	uint32_t node = kRefDone;
+	int sp = 0;
+	float best_t = 0.0f;          // closest walk: best t so far
+	uint32_t best_prim = kNoPrim; // closest walk: best primitive; any-hit walk: kNoPrim until occluded
+	bool any_hit = false;         // the walk is a shadow walk
+	// the path
 	V3 thr = v3s(1.0f), outp = v3s(0.0f), mean = v3s(0.0f), wo = v3s(0.0f);
 	Hit hit;
 	hit.t = 0.0f;
@@ -120,7 +146,50 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 	uint32_t ray_count = 0;
 	unsigned long long rays_total = 0;
 	bool primary = true;
+	// the light sample in flight (LIGHT -> shadow walk -> SCATTER).  With the fine schedule it
+	// survives loop iterations (PL below, and the shadow ray lives in `ray`); with the coarse schedule
+	// LIGHT, the shadow walk and SCATTER run back to back in one iteration, so the context and the
+	// shadow ray are locals of that iteration and the registers are free the rest of the time.
+	struct LightCtx {
+		V3 l_wi;
+		float pdf_multiplier;
+		float t_limit;  // occluders need NOT (t >= t_limit); NaN = no limit (sky)
+		uint32_t skip;  // the light primitive itself (check_hit_index skips it)
+		bool have_shadow, shadow_is_sky;
+	};
+	LightCtx PL;
+	PL.l_wi = v3s(0.0f);
+	PL.pdf_multiplier = 1.0f;
+	PL.t_limit = 0.0f;
+	PL.skip = kNoPrim;
+	PL.have_shadow = PL.shadow_is_sky = false;
 
+	// start a walk of `ray`: the root test of Bvh::get_intersection_candidates (mod.rs:203-210)
+	auto begin_walk = [&](bool shadow) {
+		any_hit = shadow;
+		best_t = 0.0f;
+		best_prim = kNoPrim;
+		sp = 0;
+		if (!FINE) { // coarse schedule: the whole walk runs inside the super-phase (walk_pending below)
+			ph = PH_NODE;
+			return;
+		}
+		float tm;
+		if (aabb_does_int(S.root_min, S.root_max, ray, tm)) {
+			node = S.root_ref;
+			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
+		} else {
+			node = kRefDone;
+			ph = shadow ? PH_SCATTER : PH_SHADE;
+		}
+	};
+	// the walk moved to `node` (inner, leaf or finished): choose the lane's next phase
+	auto after_step = [&]() {
+		if (node == kRefDone)
+			ph = any_hit ? PH_SCATTER : PH_SHADE;
+		else
+			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
+	};
 	// sample finished: filter, fold into the running mean, next sample or next pixel
 	auto finalize = [&](bool filter) {
 		V3 c = outp;
@@ -136,16 +205,311 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 			out[3u * (size_t)out_index + 0u] = mean.x;
 			out[3u * (size_t)out_index + 1u] = mean.y;
 			out[3u * (size_t)out_index + 2u] = mean.z;
-			st = ST_NEED_PIXEL;
+			ph = PH_NEED_PIXEL;
 		} else {
-			st = ST_NEW_SAMPLE;
+			ph = PH_GEN;
+		}
+	};
+
+	// GEN -- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61
+	auto do_gen = [&]() {
+		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
+		const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
+		const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
+		// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
+		ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
+		(void)rt_rng_f32(&rng);
+		thr = v3s(1.0f);
+		outp = v3s(0.0f);
+		depth = 0;
+		ray_count = 0;
+		primary = true;
+		begin_walk(false);
+	
+	};
+
+	// NODE -- one inner-node step: Bvh::get_intersection_candidates' loop body (mod.rs:203-221)
+	auto do_node = [&]() {
+		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
+		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
+		after_step();
+	
+	};
+
+	// LEAF -- one leaf: the primitive loops of Bvh::check_hit (mod.rs:270-293) / check_hit_index (:244-261)
+	auto do_leaf = [&]() {
+		uint32_t first, count;
+		leaf_range(S, node, first, count);
+		bool occluded = false;
+		for (uint32_t slot = first; slot < first + count; ++slot) {
+			if (any_hit && slot == PL.skip)
+				continue;
+			const PrimGeom g = load_prim<F>(S, slot);
+			float t;
+			if (prim_t<F>(g, ray, t) && t > 0.0f) {
+				if (any_hit) {
+					if (!(t >= PL.t_limit)) {
+						occluded = true;
+						break;
+					}
+				} else {
+					bool take;
+					if (best_prim == kNoPrim)
+						take = true;
+					else if (t < best_t)
+						take = true;
+					else if (t == best_t)
+						take = S.prim_rank[slot] < S.prim_rank[best_prim]; // first in BFS-leaf order wins
+					else
+						take = false;
+					if (take) {
+						best_t = t;
+						best_prim = slot;
+					}
+				}
+			}
+		}
+		if (occluded) {
+			best_prim = 0u; // any-hit result: anything but kNoPrim means "occluded"
+			node = kRefDone;
+		} else if (sp == 0) {
+			node = kRefDone;
+		} else {
+			--sp;
+			node = stk[sp * kStackStride];
+		}
+		after_step();
+	
+	};
+
+	// SHADE -- the walk of a path ray ended: integrators/mod.rs:31-72 (naive), mis.rs:17-33,50-86 (MIS)
+	auto do_shade = [&]() {
+		const uint32_t prim = best_prim;
+		bool finish = false;
+		bool filter = true;
+		Hit nh;
+		uint32_t nmat;
+		if (prim != kNoPrim)
+			make_hit<F>(S, prim, ray, best_t, nh, nmat);
+		else
+			make_sky_hit(S, nh, nmat);
+
+		if (METHOD == 0) {
+			// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
+			ray_count += 1;
+			const V3 wo_n = ray.d;
+			const V3 emission = mat_get_emission<F>(S, nmat, nh, wo_n);
+			const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng);
+			if (depth == 0) {
+				outp = outp + emission;
+				if (exit)
+					finish = true;
+			}
+			if (!finish && exit) {
+				outp = outp + thr * emission;
+				finish = true;
+			}
+			if (!finish) {
+				if (!mat_is_delta<F>(S, nmat))
+					thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d);
+				else
+					thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d);
+				if (depth > P.rr_threshold) {
+					const float p = component_max(thr);
+					if (rt_rng_f32(&rng) > p)
+						finish = true;
+					else
+						thr = thr / p;
+				}
+				if (!finish) {
+					depth += 1;
+					if (!(depth < P.max_depth))
+						finish = true;
+				}
+			}
+		} else if (primary) {
+			// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
+			wo = ray.d;
+			hit = nh;
+			mat = nmat;
+			const V3 emission = mat_get_emission<F>(S, mat, hit, wo);
+			Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
+			const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng);
+			outp = outp + emission;
+			if (exit) {
+				finish = true;
+				filter = false; // mis.rs:29-31 returns before the filter
+			} else {
+				depth = 1;
+				primary = false;
+				if (!(depth < P.max_depth))
+					finish = true;
+			}
+		} else {
+			// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
+			const V3 m_wi = ray.d;
+			const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi);
+			const V3 le = mat_get_emission<F>(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
+			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi);
+			if (!is_zero(le)) {
+				// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
+				// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
+				const bool on_light = F::lights && (prim != kNoPrim) && mat_is_light(S, nmat) && !mat_is_delta<F>(S, mat);
+				if (on_light || (prim == kNoPrim && sky_samplable)) {
+					// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
+					const uint32_t n_l = F::lights ? S.n_lights : 0u;
+					const float divisor = (float)(sky_samplable ? n_l + 1u : n_l);
+					float l_pdf;
+					if (prim == kNoPrim) {
+						l_pdf = sky_pdf(S, T, m_wi) / divisor;
+					} else {
+						const PrimGeom g = load_prim<F>(S, prim);
+						l_pdf = prim_scattering_pdf<F>(g, hit.point, m_wi, nh) / divisor;
+					}
+					const float mis_weight = power_heuristic(m_pdf, l_pdf);
+					outp = outp + thr * le * mis_weight;
+				} else {
+					outp = outp + thr * le;
+				}
+			}
+			if (mat_is_light(S, nmat)) {
+				finish = true;
+			} else {
+				if (depth > P.rr_threshold) {
+					const float p = component_max(thr);
+					if (rt_rng_f32(&rng) > p)
+						finish = true;
+					else
+						thr = thr / p;
+				}
+				if (!finish) {
+					wo = m_wi;
+					hit = nh;
+					mat = nmat;
+					depth += 1;
+					if (!(depth < P.max_depth))
+						finish = true;
+				}
+			}
+		}
+		if (finish)
+			finalize(filter);
+		else if (METHOD == 1)
+			ph = PH_LIGHT; // the path continues: light sampling is next
+		else
+			begin_walk(false); // naive: `ray` already is the scattered ray
+	
+	};
+
+	// LIGHT -- sample_lights up to the shadow ray  mis.rs:95-157
+	auto do_light = [&](LightCtx &L, Ray &sr) {
+		ray_count += 1; // mis.rs:38
+		L.have_shadow = false;
+		L.shadow_is_sky = false;
+		L.pdf_multiplier = 1.0f;
+		L.skip = kNoPrim;
+		const uint32_t samplable_len = F::lights ? S.n_lights : 0u;
+		bool pick_sky = false, pick_light = false;
+		uint32_t light_slot = 0;
+		if (samplable_len == 0u) {
+			pick_sky = sky_samplable; // (0,true) => sample_sky(1.0); (0,false) => None
+		} else if (!sky_samplable) {
+			L.pdf_multiplier = 1.0f / (float)samplable_len;
+			light_slot = rt_rng_below(&rng, samplable_len); // gen_range(0..len)
+			pick_light = true;
+		} else {
+			L.pdf_multiplier = 1.0f / (float)(samplable_len + 1u);
+			light_slot = rt_rng_below(&rng, samplable_len + 1u); // gen_range(0..=len)
+			if (light_slot == samplable_len)
+				pick_sky = true;
+			else
+				pick_light = true;
+		}
+		const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
+		if (pick_sky) {
+			L.l_wi = sky_sample(S, T, rng);
+			sr = ray_new<F>(shadow_origin, L.l_wi);
+			L.t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
+			L.have_shadow = true;
+			L.shadow_is_sky = true;
+		} else if (pick_light) {
+			L.skip = S.lights[light_slot];
+			const PrimGeom g = load_prim<F>(S, L.skip);
+			L.l_wi = prim_sample_visible_from_point<F>(g, hit.point, rng);
+			sr = ray_new<F>(shadow_origin, L.l_wi);
+			float lt;
+			if (prim_t<F>(g, sr, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
+				L.t_limit = lt;
+				L.have_shadow = true;
+			}
+		}
+		if (L.have_shadow) {
+			begin_walk(true);
+		} else {
+			best_prim = kNoPrim;
+			ph = PH_SCATTER;
+		}
+	
+	};
+
+	// SCATTER -- the shadow walk ended: light contribution (mis.rs:39-43) and material sampling (mis.rs:46-49)
+	auto do_scatter = [&](LightCtx &L, Ray &sr) {
+		const bool occluded = best_prim != kNoPrim;
+		if (L.have_shadow && !occluded) {
+			bool valid = false;
+			V3 le = v3s(0.0f);
+			float l_pdf = 0.0f;
+			if (L.shadow_is_sky) { // sample_sky  mis.rs:104-115
+				le = mat_get_emission<F>(S, S.sky.material, hit, L.l_wi);
+				l_pdf = sky_pdf(S, T, L.l_wi) * L.pdf_multiplier;
+				valid = true;
+			} else { // sample_light  mis.rs:117-133 (`ray` still is the shadow ray)
+				Hit lh;
+				uint32_t lm;
+				make_hit<F>(S, L.skip, sr, L.t_limit, lh, lm);
+				const PrimGeom g = load_prim<F>(S, L.skip);
+				const float p = prim_scattering_pdf<F>(g, hit.point, L.l_wi, lh);
+				if (p > 0.0f) {
+					le = mat_get_emission<F>(S, lm, lh, L.l_wi);
+					l_pdf = p * L.pdf_multiplier;
+					valid = true;
+				}
+			}
+			if (valid) { // mis.rs:39-43
+				const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, L.l_wi);
+				const float mis_weight = power_heuristic(l_pdf, m_pdf);
+				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi) * mis_weight * le / l_pdf;
+			}
+		}
+		// ---- material sampling  mis.rs:46-49.  scatter_ray reads only the incoming direction of
+		// the ray that produced `hit`, which is `wo` (mis.rs:21,82); `ray` held the shadow ray. ----
+		ray.d = wo;
+		if (mat_scatter_ray<F>(S, mat, ray, hit, rng))
+			finalize(true);
+		else
+			begin_walk(false);
+	
+	};
+
+	// coarse schedule: run the pending walk of this lane to its end with the tight while-while loops
+	// of rt_intersect.h (closest walk in the TRACE super-phase, shadow walk in the LIGHT super-phase)
+	auto walk_closest_pending = [&]() {
+		if (ph == PH_NODE && !any_hit) {
+			trace_closest<F, PRUNE>(S, ray, stk, best_t, best_prim);
+			ph = PH_SHADE;
+		}
+	};
+	auto walk_shadow_pending = [&](const LightCtx &L, const Ray &sr) {
+		if (ph == PH_NODE && any_hit) {
+			best_prim = trace_any<F, PRUNE>(S, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
+			ph = PH_SCATTER;
 		}
 	};
 
 	for (;;) {
 		// ---- work acquisition: one atomic per wave for all lanes that ran out of samples ----
 		{
-			const unsigned long long need = __ballot(st == ST_NEED_PIXEL);
+			const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
 			if (need != 0ull) {
 				const uint32_t n = (uint32_t)__popcll(need);
 				const int leader = __ffsll((long long)need) - 1;
@@ -153,252 +517,91 @@ __global__ __launch_bounds__(256) void render_kernel(const DevScene S, const Dev
 				if ((int)lane == leader)
 					base = atomicAdd(work_counter, n);
 				base = __shfl(base, leader);
-				if (st == ST_NEED_PIXEL) {
+				if (ph == PH_NEED_PIXEL) {
 					const uint32_t w = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
 					if (w >= P.n_work) {
-						st = ST_DONE;
+						ph = PH_DONE;
 					} else if (work_to_pixel(P, w, px, py)) {
 						pixel_index = py * P.width + px;
 						out_index = P.shard_layout ? w : pixel_index;
 						sample_local = 0;
 						mean = v3s(0.0f);
-						st = ST_NEW_SAMPLE;
+						ph = PH_GEN;
 					} // else: padding of an edge tile; ask again next iteration
 				}
 			}
 		}
-		// ---- phase vote.  Lanes want either the TRACE phase ([A] closest hit + [B] shade; a lane
-		// whose sample ended regenerates and stays in this phase) or the LIGHT phase ([C] light sample
-		// + shadow walk, [D] BSDF sample).  The wave runs the phase the majority waits for, the others
-		// keep their state in registers: no lane idles through a phase it has no work in. ----
-		const uint32_t n_light = (uint32_t)__popcll(__ballot(st == ST_LIGHT));
-		const uint32_t n_trace = (uint32_t)__popcll(__ballot(st == ST_NEW_SAMPLE || st == ST_TRACE));
-		if (n_light + n_trace == 0u) {
-			if (__ballot(st == ST_NEED_PIXEL) == 0ull)
-				break; // every lane is ST_DONE
-			continue;  // only edge-tile padding was handed out: ask again
-		}
-		const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
 
-		if (!run_light) {
-			// ---- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61 ----
-			if (st == ST_NEW_SAMPLE) {
-				rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
-				const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
-				const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
-				// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
-				ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
-				(void)rt_rng_f32(&rng);
-				thr = v3s(1.0f);
-				outp = v3s(0.0f);
-				depth = 0;
-				ray_count = 0;
-				primary = true;
-				st = ST_TRACE;
-			}
-			const bool act = (st == ST_TRACE);
-
-			// ---- [A] Bvh::check_hit for the lane's current ray ----
-			float best_t = 0.0f;
-			uint32_t prim = kNoPrim;
-			if (act)
-				trace_closest<F, PRUNE>(S, ray, stk, best_t, prim);
-
-			if (act) {
-				bool finish = false;
-				bool filter = true;
-				Hit nh;
-				uint32_t nmat;
-				if (prim != kNoPrim)
-					make_hit<F>(S, prim, ray, best_t, nh, nmat);
-				else
-					make_sky_hit(S, nh, nmat);
-
-				if (METHOD == 0) {
-					// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
-					ray_count += 1;
-					const V3 wo_n = ray.d;
-					const V3 emission = mat_get_emission<F>(S, nmat, nh, wo_n);
-					const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng);
-					if (depth == 0) {
-						outp = outp + emission;
-						if (exit)
-							finish = true;
-					}
-					if (!finish && exit) {
-						outp = outp + thr * emission;
-						finish = true;
-					}
-					if (!finish) {
-						if (!mat_is_delta<F>(S, nmat))
-							thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d);
-						else
-							thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d);
-						if (depth > P.rr_threshold) {
-							const float p = component_max(thr);
-							if (rt_rng_f32(&rng) > p)
-								finish = true;
-							else
-								thr = thr / p;
-						}
-						if (!finish) {
-							depth += 1;
-							if (!(depth < P.max_depth))
-								finish = true;
-						}
-					}
-				} else if (primary) {
-					// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
-					wo = ray.d;
-					hit = nh;
-					mat = nmat;
-					const V3 emission = mat_get_emission<F>(S, mat, hit, wo);
-					Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
-					const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng);
-					outp = outp + emission;
-					if (exit) {
-						finish = true;
-						filter = false; // mis.rs:29-31 returns before the filter
-					} else {
-						depth = 1;
-						primary = false;
-						if (!(depth < P.max_depth))
-							finish = true;
-					}
-				} else {
-					// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
-					const V3 m_wi = ray.d;
-					const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi);
-					const V3 le = mat_get_emission<F>(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
-					thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi);
-					if (!is_zero(le)) {
-						// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
-						// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
-						const bool on_light = F::lights && (prim != kNoPrim) && mat_is_light(S, nmat) && !mat_is_delta<F>(S, mat);
-						if (on_light || (prim == kNoPrim && sky_samplable)) {
-							// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
-							const uint32_t n_l = F::lights ? S.n_lights : 0u;
-							const float divisor = (float)(sky_samplable ? n_l + 1u : n_l);
-							float l_pdf;
-							if (prim == kNoPrim) {
-								l_pdf = sky_pdf(S, T, m_wi) / divisor;
-							} else {
-								const PrimGeom g = load_prim<F>(S, prim);
-								l_pdf = prim_scattering_pdf<F>(g, hit.point, m_wi, nh) / divisor;
-							}
-							const float mis_weight = power_heuristic(m_pdf, l_pdf);
-							outp = outp + thr * le * mis_weight;
-						} else {
-							outp = outp + thr * le;
-						}
-					}
-					if (mat_is_light(S, nmat)) {
-						finish = true;
-					} else {
-						if (depth > P.rr_threshold) {
-							const float p = component_max(thr);
-							if (rt_rng_f32(&rng) > p)
-								finish = true;
-							else
-								thr = thr / p;
-						}
-						if (!finish) {
-							wo = m_wi;
-							hit = nh;
-							mat = nmat;
-							depth += 1;
-							if (!(depth < P.max_depth))
-								finish = true;
-						}
-					}
+		if (FINE) {
+			// ---- big trees: every step is its own phase; run the one most lanes wait for
+			// (ties: the later pipeline stage) ----
+			int run = -1;
+			uint32_t best_n = 0;
+#pragma unroll
+			for (int k = 0; k < PH_COUNT; ++k) {
+				const uint32_t c = (uint32_t)__popcll(__ballot(ph == k));
+				if (c >= best_n && c > 0u) {
+					best_n = c;
+					run = k;
 				}
-				if (finish)
-					finalize(filter);
-				else if (METHOD == 1)
-					st = ST_LIGHT; // the path continues: it now waits for the light phase
+			}
+			if (run < 0) {
+				if (__ballot(ph == PH_NEED_PIXEL) == 0ull)
+					break; // every lane is PH_DONE
+				continue;  // only edge-tile padding was handed out: ask again
+			}
+			if (run == PH_NODE) {
+				if (ph == PH_NODE)
+					do_node();
+			} else if (run == PH_LEAF) {
+				if (ph == PH_LEAF)
+					do_leaf();
+			} else if (run == PH_GEN) {
+				if (ph == PH_GEN)
+					do_gen();
+			} else if (run == PH_SHADE) {
+				if (ph == PH_SHADE)
+					do_shade();
+			} else if (run == PH_LIGHT) {
+				if (ph == PH_LIGHT)
+					do_light(PL, ray);
+			} else {
+				if (ph == PH_SCATTER)
+					do_scatter(PL, ray);
 			}
 		} else {
-			// ---- [C] sample_lights  mis.rs:95-157 ----
-			const bool cont = (st == ST_LIGHT);
-			bool have_shadow = false, shadow_is_sky = false;
-			Ray sray;
-			sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
-			V3 l_wi = v3s(0.0f);
-			float pdf_multiplier = 1.0f, t_limit = 0.0f;
-			uint32_t light_prim = kNoPrim;
-			if (cont) {
-				ray_count += 1; // mis.rs:38
-				const uint32_t samplable_len = F::lights ? S.n_lights : 0u;
-				bool pick_sky = false, pick_light = false;
-				uint32_t light_slot = 0;
-				if (samplable_len == 0u) {
-					pick_sky = sky_samplable; // (0,true) => sample_sky(1.0); (0,false) => None
-				} else if (!sky_samplable) {
-					pdf_multiplier = 1.0f / (float)samplable_len;
-					light_slot = rt_rng_below(&rng, samplable_len); // gen_range(0..len)
-					pick_light = true;
-				} else {
-					pdf_multiplier = 1.0f / (float)(samplable_len + 1u);
-					light_slot = rt_rng_below(&rng, samplable_len + 1u); // gen_range(0..=len)
-					if (light_slot == samplable_len)
-						pick_sky = true;
-					else
-						pick_light = true;
-				}
-				const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
-				if (pick_sky) {
-					l_wi = sky_sample(S, T, rng);
-					sray = ray_new<F>(shadow_origin, l_wi);
-					t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
-					have_shadow = true;
-					shadow_is_sky = true;
-				} else if (pick_light) {
-					light_prim = S.lights[light_slot];
-					const PrimGeom g = load_prim<F>(S, light_prim);
-					l_wi = prim_sample_visible_from_point<F>(g, hit.point, rng);
-					sray = ray_new<F>(shadow_origin, l_wi);
-					float lt;
-					if (prim_t<F>(g, sray, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
-						t_limit = lt;
-						have_shadow = true;
-					}
-				}
+			// ---- tiny trees (a walk is a handful of steps): two super-phases.
+			//   TRACE = GEN + closest walk + SHADE     LIGHT = LIGHT + shadow walk + SCATTER
+			// About half of all SHADE outcomes end the sample; those lanes regenerate and stay in
+			// TRACE while continuing paths pile up for LIGHT, which runs once enough lanes wait. ----
+			const uint32_t n_light = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
+			const uint32_t n_trace = (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
+			if (n_light + n_trace == 0u) {
+				if (__ballot(ph == PH_NEED_PIXEL) == 0ull)
+					break;
+				continue;
 			}
-			bool occluded = false;
-			if (have_shadow)
-				occluded = trace_any<F, PRUNE>(S, sray, stk, t_limit, light_prim);
-			if (cont) {
-				if (have_shadow && !occluded) {
-					bool valid = false;
-					V3 le = v3s(0.0f);
-					float l_pdf = 0.0f;
-					if (shadow_is_sky) { // sample_sky  mis.rs:104-115
-						le = mat_get_emission<F>(S, S.sky.material, hit, l_wi);
-						l_pdf = sky_pdf(S, T, l_wi) * pdf_multiplier;
-						valid = true;
-					} else { // sample_light  mis.rs:117-133
-						Hit lh;
-						uint32_t lm;
-						make_hit<F>(S, light_prim, sray, t_limit, lh, lm);
-						const PrimGeom g = load_prim<F>(S, light_prim);
-						const float p = prim_scattering_pdf<F>(g, hit.point, l_wi, lh);
-						if (p > 0.0f) {
-							le = mat_get_emission<F>(S, lm, lh, l_wi);
-							l_pdf = p * pdf_multiplier;
-							valid = true;
-						}
-					}
-					if (valid) { // mis.rs:39-43
-						const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, l_wi);
-						const float mis_weight = power_heuristic(l_pdf, m_pdf);
-						outp = outp + thr * mat_eval<F>(S, mat, hit, wo, l_wi) * mis_weight * le / l_pdf;
-					}
-				}
-				// ---- [D] material sampling  mis.rs:46-49 ----
-				if (mat_scatter_ray<F>(S, mat, ray, hit, rng))
-					finalize(true);
-				else
-					st = ST_TRACE;
+			const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
+			if (!run_light) {
+				if (ph == PH_GEN)
+					do_gen();
+				walk_closest_pending();
+				if (ph == PH_SHADE)
+					do_shade();
+			} else {
+				LightCtx L; // loop-local: see LightCtx above
+				L.l_wi = v3s(0.0f);
+				L.pdf_multiplier = 1.0f;
+				L.t_limit = 0.0f;
+				L.skip = kNoPrim;
+				L.have_shadow = L.shadow_is_sky = false;
+				Ray sray;
+				sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
+				if (ph == PH_LIGHT)
+					do_light(L, sray);
+				walk_shadow_pending(L, sray);
+				if (ph == PH_SCATTER)
+					do_scatter(L, sray);
 			}
 		}
 	}
