@@ -403,14 +403,28 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 
 	const bool samplable = (s->dev.sky.res_x | s->dev.sky.res_y) != 0u;
 	const size_t sky_bytes = samplable ? ((size_t)s->dev.sky.res_y * (s->dev.sky.res_x + 1u) + s->dev.sky.res_y + 1u) * 4 : 0;
-	const bool sky_lds = samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024;
-	P.sky_in_lds = sky_lds ? 1u : 0u;
-	const size_t lds_bytes = render_lds_bytes(s->dev, sky_lds, 4);
+	// Sky CDF tables in LDS (next to the traversal stacks) or left in global memory: LDS only while
+	// it does not cost resident workgroups.  Tiny trees: 41 KB tables + 1-2 KB stacks still fit 3
+	// workgroups per CU, the register limit.  Deep trees: the stacks alone are tens of KB and the
+	// sky is a small share of the work, so residency (latency hiding for the node fetches) wins.
+	bool sky_lds = false;
+	size_t lds_bytes = render_lds_bytes(s->dev, false, 4);
 	if (lds_bytes > s->max_lds)
-		return fail(RT_ERR_UNSUPPORTED, "traversal stacks + sky tables exceed the LDS of one CU");
-
+		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, sky_lds, s->feature_set, lds_bytes, &blocks_per_cu));
+	HIP_TRY(render_occupancy(o->render_method, prune, false, s->feature_set, lds_bytes, &blocks_per_cu));
+	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
+		const size_t lds_with = render_lds_bytes(s->dev, true, 4);
+		int blocks_with = 0;
+		if (lds_with <= s->max_lds &&
+		    render_occupancy(o->render_method, prune, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
+		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
+			sky_lds = true;
+			lds_bytes = lds_with;
+			blocks_per_cu = blocks_with;
+		}
+	}
+	P.sky_in_lds = sky_lds ? 1u : 0u;
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;

@@ -56,6 +56,10 @@ enum : int {
 #define RT_LIGHT_PHASE_THRESHOLD 40
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
+#ifndef RT_NODE_STEPS_PER_VOTE
+#define RT_NODE_STEPS_PER_VOTE 8
+#endif
+constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_SPHERES_WAVES
 #define RT_SPHERES_WAVES 3 // waves per SIMD the spheres-only variants are register-limited to
 #endif
@@ -551,8 +555,11 @@ __global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::ligh
 				continue;  // only edge-tile padding was handed out: ask again
 			}
 			if (run == PH_NODE) {
-				if (ph == PH_NODE)
-					do_node();
+				// a few node steps per vote: a walk is tens to hundreds of them and the vote is not free
+#pragma unroll 1
+				for (int step = 0; step < kNodeStepsPerVote; ++step)
+					if (ph == PH_NODE)
+						do_node();
 			} else if (run == PH_LEAF) {
 				if (ph == PH_LEAF)
 					do_leaf();
