@@ -244,6 +244,15 @@ int rt_scene_get_lights(const rt_scene *scene, uint64_t *out, uint64_t capacity)
  * primitive of every hit leaf, the reference's own amount of work (acceleration/mod.rs:199-224,
  * 270-293), 1 = near-first with t-pruning.  All modes return the same hits. */
 int rt_scene_set_traversal(rt_scene *scene, int mode);
+/* Other knobs that change HOW the kernels run, never what they return (used by the parity tests to
+ * cover every kernel variant):
+ *   RT_TUNE_TRAVERSAL     as rt_scene_set_traversal
+ *   RT_TUNE_FEATURE_SET   0 spheres-only, 1 + triangles and emissive primitives, 2 every material /
+ *                         texture; the library picks the smallest that covers the scene, a caller may
+ *                         only raise it
+ *   RT_TUNE_SCENE_IN_LDS  1 (default): tiny scenes are staged whole into LDS; 0: read from HBM/L2 */
+typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2 } rt_tuning_key;
+int rt_scene_set_tuning(rt_scene *scene, int key, int value);
 
 /* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----
  * Renders opts->samples_per_pixel passes and returns their running mean

@@ -25,6 +25,7 @@ RT_SPLIT_SAH, RT_SPLIT_MIDDLE, RT_SPLIT_EQUAL_COUNTS = range(3)
 # enum RenderMethod (samplers/mod.rs:43-47)
 RT_METHOD_NAIVE, RT_METHOD_MIS = range(2)
 RT_LAYOUT_FRAME, RT_LAYOUT_SHARD = range(2)
+RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS = range(3)
 
 NO_INDEX = 0xFFFFFFFFFFFFFFFF  # usize::MAX
 
@@ -195,6 +196,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_primitive_order",
     "rt_scene_get_lights",
     "rt_scene_set_traversal",
+    "rt_scene_set_tuning",
     "rt_render",
     "rt_render_device",
     "rt_render_output_floats",

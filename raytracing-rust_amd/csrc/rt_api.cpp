@@ -17,7 +17,7 @@
 #include "rt_types.h"
 
 namespace rt {
-size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_block);
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block);
 hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
@@ -62,6 +62,8 @@ struct rt_scene {
 	int n_cus = 0;
 	int traversal_mode = -1; // -1 auto, 0 exhaustive (reference order of work), 1 pruned
 	int feature_set = 2;     // smallest kernel variant covering the scene: 0 spheres-only, 1 simple, 2 full
+	int min_feature_set = 0; // what the scene needs (feature_set may be forced larger for tests)
+	bool scene_lds_allowed = true;
 	size_t max_lds = 65536;
 };
 
@@ -192,6 +194,32 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
 	const float *d_sky = nullptr;
 	if ((rc = upload(s, h.sky_cdf.data(), h.sky_cdf.size(), &d_sky)) != RT_OK) return bail(rc);
+	{
+		// tiny scenes: one packed copy of every array, staged into LDS by the render kernel.  Built here
+		// (not in rt_build.cpp) because the texture records must already hold their device pointers.
+		auto pad16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+		const size_t sizes[8] = {h.dev_nodes.size() * sizeof(DevNode),      h.dev_prims.size() * sizeof(DevPrim),
+		                         h.dev_shade.size() * sizeof(DevShade),     h.prim_rank.size() * 4,
+		                         h.materials.size() * sizeof(DevMaterial),  h.textures.size() * sizeof(DevTexture),
+		                         h.dev_lights.size() * 4,                   h.big_leaves.size() * 4};
+		const void *srcs[8] = {h.dev_nodes.data(), h.dev_prims.data(), h.dev_shade.data(), h.prim_rank.data(),
+		                       h.materials.data(), h.textures.data(),  h.dev_lights.data(), h.big_leaves.data()};
+		size_t total = 0;
+		for (int i = 0; i < 8; ++i) {
+			h.blob_off[i] = (uint32_t)total;
+			total += pad16(sizes[i]);
+		}
+		if (total <= 12 * 1024) {
+			h.blob.assign(total / 4, 0u);
+			for (int i = 0; i < 8; ++i)
+				if (sizes[i])
+					std::memcpy(reinterpret_cast<char *>(h.blob.data()) + h.blob_off[i], srcs[i], sizes[i]);
+			if ((rc = upload(s, h.blob.data(), h.blob.size(), &D.blob)) != RT_OK) return bail(rc);
+			D.blob_bytes = (uint32_t)total;
+			D.off_nodes = h.blob_off[0]; D.off_prims = h.blob_off[1]; D.off_shade = h.blob_off[2]; D.off_rank = h.blob_off[3];
+			D.off_materials = h.blob_off[4]; D.off_textures = h.blob_off[5]; D.off_lights = h.blob_off[6]; D.off_big_leaves = h.blob_off[7];
+		}
+	}
 
 	D.n_nodes = (uint32_t)h.dev_nodes.size();
 	D.n_prims = (uint32_t)h.dev_prims.size();
@@ -232,11 +260,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 			s->feature_set = 1;
 		else
 			s->feature_set = 0;
-		if (const char *e = std::getenv("RT_HIP_FEATURE_SET")) { // force a LARGER variant (debugging / tests)
-			const int f = std::atoi(e);
-			if (f > s->feature_set && f <= 2)
-				s->feature_set = f;
-		}
+		s->min_feature_set = s->feature_set;
 	}
 	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
 		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
@@ -252,6 +276,26 @@ int rt_scene_set_traversal(rt_scene *s, int mode)
 		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
 	s->traversal_mode = mode;
 	return RT_OK;
+}
+
+int rt_scene_set_tuning(rt_scene *s, int key, int value)
+{
+	if (!s)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null scene");
+	switch (key) {
+	case RT_TUNE_TRAVERSAL:
+		return rt_scene_set_traversal(s, value);
+	case RT_TUNE_FEATURE_SET: // may only grow: a smaller variant would lack code the scene needs
+		if (value < s->min_feature_set || value > 2)
+			return fail(RT_ERR_INVALID_ARGUMENT, "feature set must be between the scene's own and 2");
+		s->feature_set = value;
+		return RT_OK;
+	case RT_TUNE_SCENE_IN_LDS:
+		s->scene_lds_allowed = value != 0;
+		return RT_OK;
+	default:
+		return fail(RT_ERR_INVALID_ARGUMENT, "unknown tuning key");
+	}
 }
 
 int rt_scene_counts(const rt_scene *s, uint64_t *n_nodes, uint64_t *n_primitives, uint64_t *n_lights)
@@ -407,14 +451,17 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	// it does not cost resident workgroups.  Tiny trees: 41 KB tables + 1-2 KB stacks still fit 3
 	// workgroups per CU, the register limit.  Deep trees: the stacks alone are tens of KB and the
 	// sky is a small share of the work, so residency (latency hiding for the node fetches) wins.
+	// Tiny scenes under the coarse schedule: the whole scene rides in LDS too.
+	const bool scene_lds = !prune && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
+	P.scene_in_lds = scene_lds ? 1u : 0u;
 	bool sky_lds = false;
-	size_t lds_bytes = render_lds_bytes(s->dev, false, 4);
+	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, 4);
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
 	HIP_TRY(render_occupancy(o->render_method, prune, false, s->feature_set, lds_bytes, &blocks_per_cu));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(s->dev, true, 4);
+		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, 4);
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
 		    render_occupancy(o->render_method, prune, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&

@@ -28,6 +28,8 @@ struct HostScene {
 	std::vector<DevShade> dev_shade;
 	std::vector<uint32_t> prim_rank;
 	std::vector<uint32_t> big_leaves; // pairs (first slot, count)
+	std::vector<uint32_t> blob;       // scene blob for LDS staging (empty when the scene is not tiny)
+	uint32_t blob_off[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // nodes, prims, shade, rank, materials, textures, lights, big_leaves
 	uint32_t root_ref = 0;
 	std::vector<uint32_t> dev_lights;
 	std::vector<DevMaterial> materials;

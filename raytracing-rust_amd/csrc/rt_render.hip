@@ -89,7 +89,7 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 }
 
 template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
-__global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::lights) ? 3 : RT_SPHERES_WAVES)) void render_kernel(const DevScene S, const DevCamera cam, const DevRenderParams P,
+__global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::lights) ? 3 : RT_SPHERES_WAVES)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
 {
@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::ligh
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
+
+	DevScene S = S_global;
 
 	// ---- stage the sky CDF rows + marginal CDF into LDS ----
 	SkyTables T;
@@ -117,7 +119,26 @@ __global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::ligh
 		T.row_cdf = S.sky.row_cdf;
 		T.marginal_cdf = S.sky.marginal_cdf;
 	}
-	uint32_t *stk = lds + sky_words + wave * (S.stack_depth * kStackStride) + lane;
+	// ---- tiny scenes (coarse schedule only): stage the whole scene into LDS, so the dependent loads
+	// of a walk (node -> primitive -> material -> texture) pay LDS latency instead of L1/L2 latency ----
+	uint32_t blob_words = 0;
+	if (!FINE && P.scene_in_lds) {
+		uint32_t *lds_blob = lds + sky_words;
+		blob_words = S.blob_bytes / 4u;
+		for (uint32_t i = threadIdx.x; i < blob_words; i += blockDim.x)
+			lds_blob[i] = S.blob[i];
+		__syncthreads();
+		const char *b = reinterpret_cast<const char *>(lds_blob);
+		S.nodes = reinterpret_cast<const DevNode *>(b + S.off_nodes);
+		S.prims = reinterpret_cast<const DevPrim *>(b + S.off_prims);
+		S.shade = reinterpret_cast<const DevShade *>(b + S.off_shade);
+		S.prim_rank = reinterpret_cast<const uint32_t *>(b + S.off_rank);
+		S.materials = reinterpret_cast<const DevMaterial *>(b + S.off_materials);
+		S.textures = reinterpret_cast<const DevTexture *>(b + S.off_textures);
+		S.lights = reinterpret_cast<const uint32_t *>(b + S.off_lights);
+		S.big_leaves = reinterpret_cast<const uint2 *>(b + S.off_big_leaves);
+	}
+	uint32_t *stk = lds + sky_words + blob_words + wave * (S.stack_depth * kStackStride) + lane;
 
 	const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
 	const uint64_t sample_begin = ((uint64_t)P.sample_begin_hi << 32) | P.sample_begin_lo;
@@ -709,9 +730,9 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 }
 
 // ---- launchers (called from rt_api.cpp) ----
-size_t render_lds_bytes(const DevScene &S, bool sky_lds, uint32_t waves_per_block)
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block)
 {
-	size_t words = 0;
+	size_t words = scene_lds ? S.blob_bytes / 4u : 0u;
 	if (sky_lds) {
 		const uint32_t n_all = S.sky.res_y * (S.sky.res_x + 1u) + S.sky.res_y + 1u;
 		words += (n_all + 3u) & ~3u;

@@ -99,6 +99,11 @@ struct DevScene {
 	uint32_t n_nodes, n_prims, n_lights, n_materials, n_textures;
 	uint32_t root_ref;         // child-style reference to the root (a leaf ref when the tree is one leaf)
 	float root_min[3], root_max[3];
+	// "scene blob": every array above packed into one allocation (16-byte aligned sections) so a
+	// workgroup can copy a tiny scene into LDS with one loop; offsets are in bytes, 0 bytes = no blob
+	const uint32_t *blob;
+	uint32_t blob_bytes;
+	uint32_t off_nodes, off_prims, off_shade, off_rank, off_materials, off_textures, off_lights, off_big_leaves;
 	uint32_t stack_depth;      // traversal stack entries per lane (tree depth + 1)
 	uint32_t has_triangles;
 	DevSky sky;
@@ -120,6 +125,7 @@ struct DevRenderParams {
 	int32_t shard_layout;     // 1: packed shard output
 	int32_t prune;            // t-pruned traversal (validated equal to the reference's exhaustive one)
 	uint32_t sky_in_lds;      // sky CDF tables are staged in LDS
+	uint32_t scene_in_lds;    // the scene blob is staged in LDS (tiny scenes)
 };
 
 } // namespace rt

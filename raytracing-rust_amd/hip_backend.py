@@ -124,6 +124,10 @@ class HipScene:
         """-1 auto, 0 exhaustive (reference amount of work), 1 pruned."""
         _check(lib().rt_scene_set_traversal(self._h, C.c_int(mode)))
 
+    def set_tuning(self, key, value):
+        """abi.RT_TUNE_*: knobs that change how the kernels run, never what they return."""
+        _check(lib().rt_scene_set_tuning(self._h, C.c_int(key), C.c_int(value)))
+
     # ---- Sampler::sample_image: mean over opts.samples_per_pixel passes ----
     def render(self, camera, opts):
         n = C.c_uint64()
