@@ -76,7 +76,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP back end has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # the latter: rehearse the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -104,7 +105,7 @@ def main():
         return gather.gather(shard, frame)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -121,7 +122,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     rays = D.reduce_rays(d_rays.clone(), world)
@@ -165,7 +166,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, ls.scene, ls.camera_params)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

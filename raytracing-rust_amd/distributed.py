@@ -82,7 +82,7 @@ class ShardGather:
 
     def gather(self, shard, frame=None):
         """shard: [entries, 3] on every rank.  Returns the [H, W, 3] frame on rank 0, None elsewhere."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             parts = shard
         else:
             dist.gather(shard, self.recv if self.rank == 0 else None, dst=0)
@@ -97,6 +97,6 @@ class ShardGather:
 
 def reduce_rays(rays_tensor, world):
     """SamplerProgress.rays_shot summed over shards (8 bytes)."""
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.reduce(rays_tensor, dst=0, op=dist.ReduceOp.SUM)
     return rays_tensor
