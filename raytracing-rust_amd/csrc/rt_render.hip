@@ -61,7 +61,7 @@ constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_SPHERES_WAVES
-#define RT_SPHERES_WAVES 3 // waves per SIMD the spheres-only variants are register-limited to
+#define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to
 #endif
 
 __device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt_core/src/lib.rs:36-40
@@ -88,8 +88,18 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 	return x < P.width && y < P.height;
 }
 
+// Workgroup size and register budget per feature set.  Spheres-only kernels fit 128 VGPRs = 4 waves per
+// SIMD, but three 256-thread workgroups with a 41 KB sky table each are all the LDS of a CU holds, so
+// they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1).  The larger
+// variants are register-limited to 3 (simple) or 2 (full) waves per SIMD and keep 256 threads.
+template <class F> struct KernelShape {
+	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
+	static constexpr int block = spheres_only ? 512 : 256;
+	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? 2 : (spheres_only ? RT_SPHERES_WAVES : 3);
+};
+
 template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
-__global__ __launch_bounds__(256, (F::cmat || F::ctex) ? 2 : ((F::tri || F::lights) ? 3 : RT_SPHERES_WAVES)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
+__global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_simd) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
 {
@@ -730,6 +740,8 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 }
 
 // ---- launchers (called from rt_api.cpp) ----
+uint32_t render_block_threads(int feature_set) { return feature_set == 0 ? (uint32_t)KernelShape<Feat<false, false, false, false>>::block : 256u; }
+
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block)
 {
 	size_t words = scene_lds ? S.blob_bytes / 4u : 0u;
@@ -782,7 +794,7 @@ hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_se
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess)
 		return e;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, 256, lds_bytes);
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set), lds_bytes);
 }
 
 hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
@@ -792,7 +804,7 @@ hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, 
 	render_fn fn = pick_render(method, prune, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(256), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
 	return hipGetLastError();
 }
 
