@@ -278,6 +278,15 @@ int rt_shard_pixel_order(const rt_render_opts *opts, uint64_t *out, uint64_t cap
  * (synchronises that stream).  The kernel's launch count is returned through n_launches. */
 int rt_last_kernel_ms(rt_scene *scene, float *ms, uint32_t *n_launches);
 
+/* ---- output stage, the step right after the path: crates/output/src/lib.rs:74-113 save_data_to_image.
+ * Host-side (no GPU needed).  rt_output_rgb8 is the reference's pixel conversion
+ * `(val.powf(1.0 / gamma) * 255.999) as u8` (`as u8` saturates, NaN -> 0); rt_output_save writes
+ * width*height RGB8 pixels as .png (stored deflate blocks) or .ppm, chosen by the extension the way
+ * save_data_to_image does; other extensions the reference accepts (jpg, tiff, bmp, exr) return
+ * RT_ERR_UNSUPPORTED. ---- */
+int rt_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *out);
+int rt_output_save(const char *filename, const float *rgb, uint32_t width, uint32_t height, float gamma);
+
 /* ---- AccelerationStructure::check_hit / check_hit_index for a batch of rays
  * (acceleration/mod.rs:226-298), run on the GPU; host buffers ---- */
 int rt_check_hit(rt_scene *scene, const rt_ray_desc *rays, uint64_t n_rays, rt_hit_record *out);

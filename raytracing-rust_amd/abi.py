@@ -202,6 +202,8 @@ EXPORTED_SYMBOLS = [
     "rt_render_output_floats",
     "rt_shard_pixel_order",
     "rt_last_kernel_ms",
+    "rt_output_rgb8",
+    "rt_output_save",
     "rt_check_hit",
     "rt_check_hit_index",
 ]

@@ -8,6 +8,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -541,6 +543,124 @@ int rt_last_kernel_ms(rt_scene *s, float *ms, uint32_t *n_launches)
 		*n_launches = s->n_launches;
 	return RT_OK;
 }
+
+// ---- output stage (host only): crates/output/src/lib.rs:74-113 ----
+namespace {
+
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n)
+{
+	static uint32_t table[256];
+	static bool init = false;
+	if (!init) {
+		for (uint32_t i = 0; i < 256; ++i) {
+			uint32_t c = i;
+			for (int k = 0; k < 8; ++k)
+				c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+			table[i] = c;
+		}
+		init = true;
+	}
+	for (size_t i = 0; i < n; ++i)
+		crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+	return crc;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x)
+{
+	v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+void png_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data)
+{
+	put_be32(png, (uint32_t)data.size());
+	const size_t start = png.size();
+	png.insert(png.end(), type, type + 4);
+	png.insert(png.end(), data.begin(), data.end());
+	put_be32(png, crc32_update(0xFFFFFFFFu, png.data() + start, png.size() - start) ^ 0xFFFFFFFFu);
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *out)
+{
+	if (!rgb || !out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	const float inv_gamma = 1.0f / gamma;
+	for (uint64_t i = 0; i < n_values; ++i) {
+		const float v = std::pow(rgb[i], inv_gamma) * 255.999f; // val.powf(1.0 / gamma) * 255.999
+		out[i] = !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (uint8_t)v); // `as u8`: saturating, NaN -> 0
+	}
+	return RT_OK;
+}
+
+int rt_output_save(const char *filename, const float *rgb, uint32_t width, uint32_t height, float gamma)
+{
+	if (!filename || !rgb || width == 0 || height == 0)
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	const std::string name(filename);
+	// save_data_to_image splits on '.', demands exactly one, and dispatches on the extension (lib.rs:81-88)
+	const size_t dot = name.find('.');
+	if (dot == std::string::npos || name.find('.', dot + 1) != std::string::npos)
+		return fail(RT_ERR_INVALID_ARGUMENT, "Invalid filename: exactly one '.' expected");
+	const std::string ext = name.substr(dot + 1);
+	const uint64_t n = (uint64_t)width * height * 3;
+	std::vector<uint8_t> px(n);
+	rt_output_rgb8(rgb, n, gamma, px.data());
+	std::vector<uint8_t> file;
+	if (ext == "ppm") {
+		char header[64];
+		const int len = std::snprintf(header, sizeof header, "P6\n%u %u\n255\n", width, height);
+		file.assign(header, header + len);
+		file.insert(file.end(), px.begin(), px.end());
+	} else if (ext == "png") {
+		static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+		file.assign(sig, sig + 8);
+		std::vector<uint8_t> ihdr;
+		put_be32(ihdr, width);
+		put_be32(ihdr, height);
+		const uint8_t rest[5] = {8, 2, 0, 0, 0}; // 8 bits, RGB
+		ihdr.insert(ihdr.end(), rest, rest + 5);
+		png_chunk(file, "IHDR", ihdr);
+		// scanlines with filter byte 0, wrapped in zlib "stored" blocks
+		std::vector<uint8_t> raw;
+		raw.reserve((size_t)height * (width * 3 + 1));
+		for (uint32_t y = 0; y < height; ++y) {
+			raw.push_back(0);
+			raw.insert(raw.end(), px.begin() + (size_t)y * width * 3, px.begin() + (size_t)(y + 1) * width * 3);
+		}
+		std::vector<uint8_t> z;
+		z.push_back(0x78);
+		z.push_back(0x01);
+		uint32_t a = 1, b = 0; // adler32
+		for (size_t pos = 0; pos < raw.size();) {
+			const size_t len = std::min<size_t>(65535, raw.size() - pos);
+			z.push_back(pos + len == raw.size() ? 1 : 0);
+			z.push_back((uint8_t)(len & 0xFF)); z.push_back((uint8_t)(len >> 8));
+			z.push_back((uint8_t)(~len & 0xFF)); z.push_back((uint8_t)((~len >> 8) & 0xFF));
+			z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+			for (size_t i = pos; i < pos + len; ++i) {
+				a = (a + raw[i]) % 65521u;
+				b = (b + a) % 65521u;
+			}
+			pos += len;
+		}
+		put_be32(z, (b << 16) | a);
+		png_chunk(file, "IDAT", z);
+		png_chunk(file, "IEND", {});
+	} else {
+		return fail(RT_ERR_UNSUPPORTED, "Unable to save file: only .png and .ppm are implemented (unknown or unsupported filetype ." + ext + ")");
+	}
+	FILE *f = std::fopen(filename, "wb");
+	if (!f)
+		return fail(RT_ERR_INVALID_ARGUMENT, "cannot open output file");
+	const size_t written = std::fwrite(file.data(), 1, file.size(), f);
+	std::fclose(f);
+	if (written != file.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "short write");
+	return RT_OK;
+}
+
+} // extern "C"
 
 // ---- batch hit queries ----
 static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n, rt_hit_record *out)

@@ -236,3 +236,18 @@ def running_mean_update(image, progress, i):
     n = progress.samples_completed
     image += (progress.current_image - image) * (np.float32(n) / np.float32(i))
     return False
+
+
+def output_rgb8(image, gamma=2.2):
+    """save_data_to_image's pixel conversion (crates/output/src/lib.rs:92-95): (v.powf(1/gamma) * 255.999) as u8."""
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _check(lib().rt_output_rgb8(_p(a, C.c_float), C.c_uint64(a.size), C.c_float(gamma), _p(out, C.c_uint8)))
+    return out
+
+
+def save_image(filename, image, gamma=2.2):
+    """save_data_to_image (crates/output/src/lib.rs:74-113): .png or .ppm by extension."""
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    h, w, _ = a.shape
+    _check(lib().rt_output_save(filename.encode(), _p(a, C.c_float), C.c_uint32(w), C.c_uint32(h), C.c_float(gamma)))

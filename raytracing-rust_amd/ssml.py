@@ -141,7 +141,107 @@ class LoadedScene:
         self.camera_params = camera_params  # dict for rt_camera_new
 
 
-def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0):
+def resolve_path(path, base_dir):
+    """The reference opens the path as given (relative to the process cwd, loader/src/obj.rs:12); as a
+    convenience a relative path that does not exist there is also tried next to the scene file."""
+    import os
+    if os.path.isabs(path) or os.path.exists(path) or base_dir is None:
+        return path
+    return os.path.join(base_dir, path)
+
+
+def parse_obj(text):
+    """Wavefront OBJ as the `wavefront_obj` 10.0 crate presents it to loader/src/obj.rs:11-61: a list of
+    objects, each with its OWN vertex / normal arrays (indices made object-relative) and its faces grouped
+    by `usemtl`; polygons are fan-triangulated, points and lines are ignored by the loader.
+    -> [ {"name", "vertices" [n,3] f32, "normals" [m,3] f32, "geometry": [(material_name|None, [(v,vn|None)x3, ...])]} ]"""
+    objects = []
+    cur = None
+    v_base = n_base = t_base = 0
+    v_total = n_total = t_total = 0
+
+    def new_object(name):
+        nonlocal cur, v_base, n_base, t_base
+        cur = {"name": name, "vertices": [], "normals": [], "geometry": []}
+        objects.append(cur)
+        v_base, n_base, t_base = v_total, n_total, t_total
+
+    def cur_geometry(material):
+        if not cur["geometry"] or cur["geometry"][-1][0] != material:
+            cur["geometry"].append((material, []))
+        return cur["geometry"][-1][1]
+
+    material = None
+    for raw in text.splitlines():
+        line = raw.split("#", 1)[0].strip()
+        if not line:
+            continue
+        tok = line.split()
+        key, args = tok[0], tok[1:]
+        if key == "o":
+            new_object(args[0] if args else "")
+            material = None
+        elif key == "v":
+            if cur is None:
+                new_object("")
+            cur["vertices"].append([np.float32(float(a)) for a in args[:3]])
+            v_total += 1
+        elif key == "vn":
+            if cur is None:
+                new_object("")
+            cur["normals"].append([np.float32(float(a)) for a in args[:3]])
+            n_total += 1
+        elif key == "vt":
+            t_total += 1
+        elif key == "usemtl":
+            material = args[0] if args else None
+        elif key == "f":
+            if cur is None:
+                new_object("")
+            corners = []
+            for a in args:
+                parts = a.split("/")
+                vi = int(parts[0])
+                vi = vi - 1 - v_base if vi > 0 else len(cur["vertices"]) + vi
+                ni = None
+                if len(parts) >= 3 and parts[2] != "":
+                    ni = int(parts[2])
+                    ni = ni - 1 - n_base if ni > 0 else len(cur["normals"]) + ni
+                corners.append((vi, ni))
+            shapes = cur_geometry(material)
+            for k in range(1, len(corners) - 1):  # fan triangulation
+                shapes.append((corners[0], corners[k], corners[k + 1]))
+    for o in objects:
+        o["vertices"] = np.asarray(o["vertices"], dtype=np.float32).reshape(-1, 3)
+        o["normals"] = np.asarray(o["normals"], dtype=np.float32).reshape(-1, 3)
+    return objects
+
+
+def add_obj(sc, path, lookup_material):
+    """load_obj (loader/src/obj.rs:11-61): one MeshData per object, one MeshTriangle per triangle, material
+    by `usemtl` name looked up among the SCENE's materials, name "default" when the group has none,
+    falling back to the default material; triangles without vertex normals are an error."""
+    with open(path, "r") as f:
+        objects = parse_obj(f.read())
+    for o in objects:
+        mesh = sc.mesh(o["vertices"], o["normals"] if len(o["normals"]) else np.zeros((1, 3), np.float32))
+        pi, ni, mats = [], [], []
+        for material_name, shapes in o["geometry"]:
+            mat = lookup_material(material_name if material_name is not None else "default")
+            for tri in shapes:
+                if any(c[1] is None for c in tri):
+                    raise SsmlError("Please export obj file with vertex normals!")
+                for c in tri:
+                    if not (0 <= c[0] < len(o["vertices"])) or not (0 <= c[1] < len(o["normals"])):
+                        raise SsmlError(f"obj index out of range in object '{o['name']}'")
+                pi.append([c[0] for c in tri])
+                ni.append([c[1] for c in tri])
+                mats.append(mat)
+        if pi:
+            sc.mesh_triangles_bulk(mesh, np.asarray(pi, np.uint32), np.asarray(ni, np.uint32), np.asarray(mats, np.uint32))
+
+
+def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0, base_dir=None):
     objects = parse(src)
     sc = SceneDescription(split_type)
     tex_by_name, mat_by_name = {}, {}
@@ -256,7 +356,10 @@ def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0):
                 raise SsmlError("expected point_one and point_two on aacuboid")
             sc.aacuboid(p1, p2, mat_of(p))
         elif mtype == "mesh":
-            raise SsmlError("Wavefront OBJ meshes are not supported yet (SURVEY 8(f1))")
+            path = p.text("obj")
+            if path is None:
+                raise SsmlError("expected obj on mesh, found nothing")
+            add_obj(sc, resolve_path(path, base_dir), lambda name: mat_by_name.get(name, mat_by_name["__DEFAULT_MAT"]))
         else:
             raise SsmlError(f"required a known value for mesh type, found '{mtype}'")
 
@@ -264,8 +367,9 @@ def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0):
 
 
 def load_file(path, **kw):
+    import os
     with open(path, "r") as f:
-        return load_str(f.read(), **kw)
+        return load_str(f.read(), base_dir=os.path.dirname(os.path.abspath(path)), **kw)
 
 
 def perlin_tables(seed=0):

@@ -25,7 +25,7 @@ W, H = 64, 36
 
 
 def cases():
-    for name in ("rtweekend1", "overshadowed"):
+    for name in ("rtweekend1", "overshadowed", "pyramid"):
         ls = scenes.load_ssml(name)
         yield name, ls.scene, ls.camera_params, 16
     yield "all_materials", scenes.all_materials(), scenes.ALL_MATERIALS_CAMERA, 8

@@ -69,6 +69,7 @@ def test_golden_images(O, golden_dir):
     cases = {
         "rtweekend1": (scenes.load_ssml("rtweekend1").scene, scenes.load_ssml("rtweekend1").camera_params, 16),
         "overshadowed": (scenes.load_ssml("overshadowed").scene, scenes.load_ssml("overshadowed").camera_params, 16),
+        "pyramid": (scenes.load_ssml("pyramid").scene, scenes.load_ssml("pyramid").camera_params, 16),
         "all_materials": (scenes.all_materials(), scenes.ALL_MATERIALS_CAMERA, 8),
         "mesh2000": (scenes.random_triangle_mesh(2000, seed=42, extent=3.0, edge=0.5, emissive_every=100, sampler_res=(20, 10)),
                      scenes.MESH_CAMERA | {"origin": (0.0, -9.0, 0.0)}, 8),

@@ -142,3 +142,32 @@ def test_primitive_record_layout_of_bulk_builder():
     assert list(d.primitives[3].u.mesh_triangle.normal_indices) == [3, 3, 3]
     assert d.primitives[10].type == abi.RT_PRIM_SPHERE and d.primitives[10].u.sphere.radius == 4.0
     assert C.sizeof(abi.PrimitiveDesc) == 40
+
+
+def test_obj_mesh_loader():
+    """`mesh ( type mesh, obj <file> )` -> loader/src/obj.rs:11-61 semantics"""
+    ls = scenes.load_ssml("pyramid")
+    d = ls.scene.desc()
+    assert d.n_meshes == 2  # one MeshData per `o` object
+    assert d.meshes[0].n_vertices == 5 and d.meshes[0].n_normals == 5
+    assert d.meshes[1].n_vertices == 4 and d.meshes[1].n_normals == 1  # indices become object-relative
+    assert d.n_primitives == 2 + 2 + 2 + 2  # quad fan (2) + 2 glow + 2 stone + slab (2)
+    stone = [i for i in range(d.n_materials) if d.materials[i].type == abi.RT_MAT_LAMBERTIAN and d.materials[i].param == np.float32(0.8)][0]
+    glow = [i for i in range(d.n_materials) if d.materials[i].type == abi.RT_MAT_EMIT and d.materials[i].param == 3.0][0]
+    mats = [d.primitives[i].material for i in range(d.n_primitives)]
+    assert mats[:6] == [stone, stone, glow, glow, stone, stone]
+    default_mat = [i for i in range(d.n_materials) if d.materials[i].type == abi.RT_MAT_LAMBERTIAN and d.materials[i].param == 0.25][0]
+    assert mats[6:] == [default_mat, default_mat]  # no usemtl -> "default" -> not found -> __DEFAULT_MAT
+    q0, q1 = d.primitives[0], d.primitives[1]
+    assert list(q0.u.mesh_triangle.point_indices) == [0, 1, 2] and list(q1.u.mesh_triangle.point_indices) == [0, 2, 3]
+    s0, s1 = d.primitives[6], d.primitives[7]
+    assert s0.u.mesh_triangle.mesh == 1 and list(s0.u.mesh_triangle.point_indices) == [0, 2, 1]
+    assert list(s1.u.mesh_triangle.point_indices) == [0, 3, 2] and list(s1.u.mesh_triangle.normal_indices) == [0, 0, 0]  # negative indices
+
+
+def test_obj_without_normals_is_rejected(tmp_path):
+    (tmp_path / "a.obj").write_text("o a\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "a.ssml").write_text("camera (\n)\nmesh (\n\ttype mesh\n\tobj a.obj\n)\n")
+    with pytest.raises(ssml.SsmlError) as e:
+        ssml.load_file(str(tmp_path / "a.ssml"))
+    assert "vertex normals" in str(e.value)
