@@ -110,3 +110,16 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in text.lower().replace("oracle/ (the cpu checker)", ""), os.path.join(dirpath, f)
     out = subprocess.run(["ldd", os.path.join(pkg_dir, "librt_hip.so")], capture_output=True, text=True).stdout
     assert "liboracle" not in out
+
+
+def test_cpp_host_header_compiles_and_fails_loudly_without_a_gpu(hb, tmp_path):
+    """include/rt_hip.hpp + tests/cpp/host_demo.cpp: a compiled host above the C ABI"""
+    exe = str(tmp_path / "host_demo")
+    lib_dir = os.path.join(ROOT, "raytracing-rust_amd")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "host_demo.cpp"), "-o", exe, "-L", lib_dir, "-lrt_hip",
+                    f"-Wl,-rpath,{lib_dir}"], check=True)
+    if hb.device_count() > 0:
+        pytest.skip("a GPU is present; the GPU-side check is tests/test_gpu_parity.py")
+    r = subprocess.run([exe, str(tmp_path / "o.f32"), str(tmp_path / "o.png"), "8", "8", "1", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
