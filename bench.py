@@ -93,6 +93,16 @@ def main():
     cam = hb.camera_new(**ls.camera_params)
 
     opts = abi.default_render_opts(WIDTH, HEIGHT, SPP, method=abi.RT_METHOD_MIS, seed=SEED)
+    # A lane folds a whole pixel by default (the reference's sequential running mean), so a GPU cannot
+    # use more lanes than it owns pixels.  One GPU owns 2.07 M pixels for 262 144 resident lanes: fine.
+    # Sharded over N GPUs each owns 1/N of them, so the passes of a pixel are split into S chunks
+    # (rt_render_opts.sample_split: same samples, chunk means combined in fixed order, image moves by
+    # ~1e-7) with S the power of two that keeps >= 4 work items per lane.  N = 1 keeps S = 1.
+    lanes = 262144
+    split = 1
+    while world > 1 and (WIDTH * HEIGHT // world) * split < 4 * lanes and split < SPP // 64:
+        split *= 2
+    opts.sample_split = split
     sopts = D.shard_opts(opts, rank, world)
     gather = D.ShardGather(opts, rank, world, device)
     shard = gather.new_shard_buffer()
@@ -153,6 +163,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"scenes/{SCENE}.ssml {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={SEED}",
                        "parallelism": f"tile-sharded x{world}, replicated BVH, one RCCL gather per frame" if world > 1 else "1 GPU",
+                       "sample_split": split,
                        "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
                        "scene_build_s": build_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -505,6 +505,8 @@ typedef struct render_job {
 	const rt_camera *camera;
 	rt_render_opts opts;
 	float *mean; /* W*H*3 running mean (the TUI's presentation buffer, src/main.rs:160-185) */
+	float *acc;  /* sample_split > 1: sum over finished chunks of mean_c * n_c */
+	uint32_t split;
 	uint64_t n_chunks;
 	atomic_uint_fast64_t next_chunk;
 	atomic_uint_fast64_t rays_shot;
@@ -530,7 +532,18 @@ static void render_chunk(render_job *j, uint64_t chunk_i, uint64_t pass, ora_ctx
 	const uint64_t first = chunk_i * PIXEL_CHUNK_SIZE;
 	const uint64_t last = first + PIXEL_CHUNK_SIZE < pixel_num ? first + PIXEL_CHUNK_SIZE : pixel_num;
 	const uint64_t sample_index = j->opts.sample_begin + pass;
-	const float i_f = (float)(pass + 1); /* the callback's `i as Float` */
+	/* sample_split (rt_hip.h): chunk c holds passes [floor(c*spp/S), floor((c+1)*spp/S)) and is folded
+	 * with its own i = 1..n_c; with S = 1 this is the callback's `i as Float` = pass + 1 */
+	const uint64_t spp = j->opts.samples_per_pixel, S = j->split;
+	uint64_t chunk = pass * S / spp;
+	while ((chunk + 1) * spp / S <= pass)
+		chunk++;
+	while (chunk * spp / S > pass)
+		chunk--;
+	const uint64_t chunk_begin = chunk * spp / S, chunk_end = (chunk + 1) * spp / S;
+	const float i_f = (float)(pass - chunk_begin + 1);
+	const bool chunk_starts = pass == chunk_begin, chunk_ends = pass + 1 == chunk_end;
+	const float n_c = (float)(chunk_end - chunk_begin);
 	uint64_t rays_shot = 0;
 	for (uint64_t pixel_i = first; pixel_i < last; ++pixel_i) {
 		const uint64_t x = pixel_i % width;
@@ -549,9 +562,19 @@ static void render_chunk(render_job *j, uint64_t chunk_i, uint64_t pass, ora_ctx
 		rays_shot += rc;
 		/* src/main.rs:179-185: *pres += (acc - *pres) / i as Float */
 		float *pres = &j->mean[pixel_i * 3];
+		if (S > 1 && chunk_starts)
+			pres[0] = pres[1] = pres[2] = 0.0f;
 		pres[0] += (rgb.x - pres[0]) / i_f;
 		pres[1] += (rgb.y - pres[1]) / i_f;
 		pres[2] += (rgb.z - pres[2]) / i_f;
+		if (S > 1 && chunk_ends) {
+			float *a = &j->acc[pixel_i * 3];
+			for (int k = 0; k < 3; ++k)
+				a[k] = a[k] + pres[k] * n_c;
+			if (pass + 1 == spp)
+				for (int k = 0; k < 3; ++k)
+					pres[k] = a[k] / (float)spp;
+		}
 	}
 	atomic_fetch_add(&j->rays_shot, rays_shot);
 }
@@ -604,6 +627,10 @@ int ora_render(const ora_scene *scene, const rt_camera *camera, const rt_render_
 	job.camera = camera;
 	job.opts = *opts;
 	job.mean = out_rgb;
+	job.split = opts->sample_split > 1 ? opts->sample_split : 1;
+	if (job.split > opts->samples_per_pixel)
+		return fail(RT_ERR_INVALID_ARGUMENT, "sample_split larger than samples_per_pixel");
+	job.acc = job.split > 1 ? (float *)calloc(opts->width * opts->height * 3, sizeof(float)) : NULL;
 	job.tile_w = opts->tile_width ? opts->tile_width : 8;
 	job.tile_h = opts->tile_height ? opts->tile_height : 8;
 	const uint64_t pixel_num = opts->width * opts->height;
@@ -642,6 +669,7 @@ int ora_render(const ora_scene *scene, const rt_camera *camera, const rt_render_
 		}
 	}
 	pthread_barrier_destroy(&job.barrier);
+	free(job.acc);
 	free(job.thread_counters);
 	free(threads);
 	free(args);

@@ -134,6 +134,8 @@ class RenderOpts(C.Structure):
         ("tile_width", C.c_uint32),
         ("tile_height", C.c_uint32),
         ("output_layout", C.c_int32),
+        ("sample_split", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 
@@ -176,7 +178,7 @@ EXPECTED_SIZES = {
     "rt_sky_desc": (SkyDesc, 16),
     "rt_scene_desc": (SceneDesc, 96),
     "rt_camera": (Camera, 48),
-    "rt_render_opts": (RenderOpts, 72),
+    "rt_render_opts": (RenderOpts, 80),
     "rt_hit_record": (HitRecord, 72),
     "rt_ray_desc": (RayDesc, 24),
     "rt_bvh_node": (BvhNode, 56),
@@ -222,4 +224,6 @@ def default_render_opts(width=1920, height=1080, spp=128, method=RT_METHOD_MIS, 
     o.shard_index, o.shard_count = 0, 1
     o.tile_width = o.tile_height = 0
     o.output_layout = RT_LAYOUT_FRAME
+    o.sample_split = 1
+    o.reserved0 = 0
     return o

@@ -25,6 +25,7 @@ hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_se
 hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter);
+hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
@@ -67,6 +68,8 @@ struct rt_scene {
 	int feature_set = 2;     // smallest kernel variant covering the scene: 0 spheres-only, 1 simple, 2 full
 	int min_feature_set = 0; // what the scene needs (feature_set may be forced larger for tests)
 	bool scene_lds_allowed = true;
+	float *d_partial = nullptr; // sample_split > 1: per-chunk means, grown on demand
+	size_t partial_floats = 0;
 	size_t max_lds = 65536;
 };
 
@@ -108,6 +111,7 @@ void rt_render_opts_default(rt_render_opts *o)
 	o->rr_threshold = 3; // integrators/mod.rs:8
 	o->shard_count = 1;
 	o->output_layout = RT_LAYOUT_FRAME;
+	o->sample_split = 1;
 }
 
 int rt_camera_new(rt_camera *out, const float origin[3], const float lookat[3], const float vup[3], float fov_degrees,
@@ -126,6 +130,8 @@ void rt_scene_destroy(rt_scene *s)
 	(void)hipSetDevice(s->device);
 	for (void *p : s->allocations)
 		(void)hipFree(p);
+	if (s->d_partial)
+		(void)hipFree(s->d_partial);
 	if (s->ev_start)
 		(void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop)
@@ -441,6 +447,26 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.tiles_x = g.tiles_x;
 	P.tiles_y = g.tiles_y;
 	P.n_work = (uint32_t)g.n_work;
+	const uint32_t split = o->sample_split > 1u ? o->sample_split : 1u;
+	if (split > o->samples_per_pixel)
+		return fail(RT_ERR_INVALID_ARGUMENT, "sample_split larger than samples_per_pixel");
+	if (g.n_work * split >= (1ull << 32))
+		return fail(RT_ERR_UNSUPPORTED, "pixels x sample_split exceeds 2^32 work items");
+	P.sample_split = split;
+	P.n_items = (uint32_t)(g.n_work * split);
+	float *render_target = d_out_rgb;
+	if (split > 1u) { // chunk means land in a scratch buffer; combine_chunks_kernel folds them into d_out_rgb
+		const size_t need = (size_t)g.n_work * split * 3;
+		if (need > s->partial_floats) { // grows on first use only (not capturable into a graph on that call)
+			if (s->d_partial)
+				(void)hipFree(s->d_partial);
+			s->d_partial = nullptr;
+			s->partial_floats = 0;
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_partial), need * sizeof(float)));
+			s->partial_floats = need;
+		}
+		render_target = s->d_partial;
+	}
 	P.shard_layout = o->output_layout == RT_LAYOUT_SHARD ? 1 : 0;
 
 	// traversal: exhaustive (the reference's own amount of work) for tiny trees where pruning cannot
@@ -478,7 +504,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
-	const uint64_t blocks_needed = (g.n_work + render_block_threads(s->feature_set) - 1) / render_block_threads(s->feature_set);
+	const uint64_t blocks_needed = ((uint64_t)P.n_items + render_block_threads(s->feature_set) - 1) / render_block_threads(s->feature_set);
 	if (n_blocks > blocks_needed)
 		n_blocks = blocks_needed ? blocks_needed : 1;
 
@@ -497,9 +523,11 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	std::memcpy(cam.vertical, camera->vertical, 12);
 
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
-	HIP_TRY(launch_render(o->render_method, prune, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, d_out_rgb,
+	HIP_TRY(launch_render(o->render_method, prune, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
+	if (split > 1u)
+		HIP_TRY(launch_combine(stream, P, s->d_partial, d_out_rgb));
 	s->timed = true;
 	s->n_launches = 1;
 	return RT_OK;

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	hit.has_uv = hit.out = false;
 	uint32_t mat = 0;
 	uint32_t depth = 0, sample_local = 0, out_index = 0, pixel_index = 0, px = 0, py = 0;
+	uint32_t chunk_begin = 0, chunk_n = P.spp; // the passes [chunk_begin, chunk_begin + chunk_n) this lane folds for its pixel
 	uint32_t ray_count = 0;
 	unsigned long long rays_total = 0;
 	bool primary = true;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		mean.z += (c.z - mean.z) / i_f;
 		rays_total += ray_count;
 		sample_local += 1;
-		if (sample_local == P.spp) {
+		if (sample_local == chunk_n) {
 			out[3u * (size_t)out_index + 0u] = mean.x;
 			out[3u * (size_t)out_index + 1u] = mean.y;
 			out[3u * (size_t)out_index + 2u] = mean.z;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 
 	// GEN -- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61
 	auto do_gen = [&]() {
-		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + sample_local);
+		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + chunk_begin + sample_local);
 		const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
 		const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
 		// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
@@ -554,11 +555,20 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 				base = __shfl(base, leader);
 				if (ph == PH_NEED_PIXEL) {
 					const uint32_t w = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-					if (w >= P.n_work) {
+					if (w >= P.n_items) {
 						ph = PH_DONE;
-					} else if (work_to_pixel(P, w, px, py)) {
+					} else if (work_to_pixel(P, P.sample_split > 1u ? w % P.n_work : w, px, py)) {
 						pixel_index = py * P.width + px;
-						out_index = P.shard_layout ? w : pixel_index;
+						if (P.sample_split > 1u) {
+							// sample_split (rt_hip.h): this item is chunk c of its pixel; its mean goes to the
+							// partial buffer (chunk-major) and combine_chunks_kernel folds the chunks in order
+							const uint32_t c = w / P.n_work;
+							chunk_begin = (uint32_t)(((uint64_t)c * P.spp) / P.sample_split);
+							chunk_n = (uint32_t)(((uint64_t)(c + 1u) * P.spp) / P.sample_split) - chunk_begin;
+							out_index = w;
+						} else {
+							out_index = P.shard_layout ? w : pixel_index;
+						}
 						sample_local = 0;
 						mean = v3s(0.0f);
 						ph = PH_GEN;
@@ -651,6 +661,37 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		if (lane == 0u)
 			atomicAdd(rays_shot, rays_total);
 	}
+}
+
+// ---- sample_split > 1: fold the per-chunk means of every pixel, in chunk order:
+// (sum_c mean_c * n_c) / spp in f32 (the definition in rt_hip.h) ----
+__global__ __launch_bounds__(256) void combine_chunks_kernel(const DevRenderParams P, const float *__restrict__ partial, float *__restrict__ out)
+{
+	const uint32_t wp = blockIdx.x * blockDim.x + threadIdx.x;
+	if (wp >= P.n_work)
+		return;
+	uint32_t x, y;
+	if (!work_to_pixel(P, wp, x, y))
+		return; // edge-tile padding
+	V3 acc = v3s(0.0f);
+	for (uint32_t c = 0; c < P.sample_split; ++c) {
+		const uint32_t b = (uint32_t)(((uint64_t)c * P.spp) / P.sample_split);
+		const float n_c = (float)((uint32_t)(((uint64_t)(c + 1u) * P.spp) / P.sample_split) - b);
+		const float *m = partial + 3u * ((size_t)c * P.n_work + wp);
+		acc.x = acc.x + m[0] * n_c;
+		acc.y = acc.y + m[1] * n_c;
+		acc.z = acc.z + m[2] * n_c;
+	}
+	const size_t o = P.shard_layout ? (size_t)wp : (size_t)y * P.width + x;
+	out[3u * o + 0u] = acc.x / (float)P.spp;
+	out[3u * o + 1u] = acc.y / (float)P.spp;
+	out[3u * o + 2u] = acc.z / (float)P.spp;
+}
+
+hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out)
+{
+	hipLaunchKernelGGL(combine_chunks_kernel, dim3((P.n_work + 255u) / 256u), dim3(256), 0, stream, P, partial, out);
+	return hipGetLastError();
 }
 
 // ---- batch hit queries (AccelerationStructure::check_hit / check_hit_index) ----

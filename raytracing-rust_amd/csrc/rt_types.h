@@ -122,6 +122,8 @@ struct DevRenderParams {
 	uint32_t shard_index, shard_count;
 	uint32_t tile_w, tile_h, tiles_x, tiles_y;
 	uint32_t n_work;          // pixels this launch owns (incl. out-of-image padding of edge tiles)
+	uint32_t sample_split;    // S: chunks per pixel (1 = the reference's strictly sequential fold)
+	uint32_t n_items;         // n_work * S work items, chunk-major: item w = chunk (w / n_work) of pixel (w % n_work)
 	int32_t shard_layout;     // 1: packed shard output
 	int32_t prune;            // t-pruned traversal (validated equal to the reference's exhaustive one)
 	uint32_t sky_in_lds;      // sky CDF tables are staged in LDS

@@ -160,3 +160,34 @@ def test_max_depth_is_a_parameter(O):
     o50 = abi.default_render_opts(40, 24, 8); o50.max_depth = 50
     c, rc = s.render(cam, o50)
     assert np.array_equal(b, c) and rb == rc  # 50 is the default
+
+
+def test_sample_split_is_a_reordering_of_the_same_samples(O):
+    """rt_render_opts.sample_split: S chunks per pixel, each folded on its own, combined in chunk order as
+    (sum mean_c * n_c) / spp.  S = 1 is the reference's strictly sequential fold (golden images); any S
+    uses the same samples and streams, so the image moves only by float rounding."""
+    ls = scenes.load_ssml("overshadowed")
+    s = O.Scene(ls.scene); cam = O.camera_new(**ls.camera_params)
+    base, rays = s.render(cam, abi.default_render_opts(48, 27, 10))
+    for S in (1, 2, 3, 10):
+        o = abi.default_render_opts(48, 27, 10); o.sample_split = S
+        img, r = s.render(cam, o, n_threads=3)
+        assert r == rays and np.abs(img - base).max() < 2e-6
+        assert np.array_equal(img, base) == (S == 1)
+    # hand check of the definition on one pixel: chunks [0,3) [3,6) [6,10) for S = 3, spp = 10
+    per_pass = []
+    for k in range(10):
+        o = abi.default_render_opts(48, 27, 1); o.sample_begin = k
+        per_pass.append(s.render(cam, o)[0][20, 30].astype(np.float32))
+    want = np.zeros(3, np.float32)
+    for (b, e) in ((0, 3), (3, 6), (6, 10)):
+        m = np.zeros(3, np.float32)
+        for i, k in enumerate(range(b, e), start=1):
+            m = m + (per_pass[k] - m) / np.float32(i)
+        want = want + m * np.float32(e - b)
+    want = want / np.float32(10)
+    o = abi.default_render_opts(48, 27, 10); o.sample_split = 3
+    assert np.array_equal(s.render(cam, o)[0][20, 30], want)
+    o.sample_split = 11
+    with pytest.raises(O.OracleError):
+        s.render(cam, o)
