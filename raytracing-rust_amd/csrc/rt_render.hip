@@ -56,6 +56,7 @@ enum : int {
 #define RT_LIGHT_PHASE_THRESHOLD 40
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
+constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
 #ifndef RT_NODE_STEPS_PER_VOTE
 #define RT_NODE_STEPS_PER_VOTE 8
 #endif
@@ -542,19 +543,28 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		}
 	};
 
+	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
 	for (;;) {
-		// ---- work acquisition: one atomic per wave for all lanes that ran out of samples ----
+		// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
+		// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
+		// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and
+		// with sample_split there can be tens of millions of items).  All of this is wave-uniform. ----
 		{
 			const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
 			if (need != 0ull) {
 				const uint32_t n = (uint32_t)__popcll(need);
-				const int leader = __ffsll((long long)need) - 1;
-				uint32_t base = 0;
-				if ((int)lane == leader)
-					base = atomicAdd(work_counter, n);
-				base = __shfl(base, leader);
+				const uint32_t avail = wq_end - wq_next;
+				uint32_t base = wq_end;
+				if (avail < n) {
+					const int leader = __ffsll((long long)need) - 1;
+					uint32_t claimed = 0;
+					if ((int)lane == leader)
+						claimed = atomicAdd(work_counter, kClaim);
+					base = __shfl(claimed, leader);
+				}
 				if (ph == PH_NEED_PIXEL) {
-					const uint32_t w = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+					const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+					const uint32_t w = r < avail ? wq_next + r : base + (r - avail);
 					if (w >= P.n_items) {
 						ph = PH_DONE;
 					} else if (work_to_pixel(P, P.sample_split > 1u ? w % P.n_work : w, px, py)) {
@@ -574,9 +584,14 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 						ph = PH_GEN;
 					} // else: padding of an edge tile; ask again next iteration
 				}
+				if (avail < n) { // the leftovers went first, the rest came from the new block
+					wq_next = base + (n - avail);
+					wq_end = base + kClaim;
+				} else {
+					wq_next += n;
+				}
 			}
 		}
-
 		if (FINE) {
 			// ---- big trees: every step is its own phase; run the one most lanes wait for
 			// (ties: the later pipeline stage) ----
