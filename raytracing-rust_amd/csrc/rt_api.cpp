@@ -428,6 +428,14 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		return fail(RT_ERR_INVALID_ARGUMENT, "unknown output layout");
 	HIP_TRY(hipSetDevice(s->device));
 	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+	if (g.n_work == 0) { // this shard owns no tile (more shards than tiles)
+		if (o->output_layout == RT_LAYOUT_FRAME)
+			HIP_TRY(hipMemsetAsync(d_out_rgb, 0, o->width * o->height * 3 * sizeof(float), stream));
+		if (d_rays_shot)
+			HIP_TRY(hipMemsetAsync(d_rays_shot, 0, sizeof(uint64_t), stream));
+		s->timed = false;
+		return RT_OK;
+	}
 
 	DevRenderParams P;
 	std::memset(&P, 0, sizeof P);
@@ -535,12 +543,19 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 
 int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, float *out_rgb, uint64_t *rays_shot)
 {
-	if (!s || !camera || !o || !out_rgb)
+	if (!s || !camera || !o)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	uint64_t n_floats = 0;
 	int rc = rt_render_output_floats(o, &n_floats);
 	if (rc != RT_OK)
 		return rc;
+	if (n_floats == 0) { // a shard that owns no tile: nothing to render, nothing to write
+		if (rays_shot)
+			*rays_shot = 0;
+		return RT_OK;
+	}
+	if (!out_rgb)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_out = nullptr;
 	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), n_floats * sizeof(float)));

@@ -99,6 +99,11 @@ template <class F> struct KernelShape {
 	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? 2 : (spheres_only ? RT_SPHERES_WAVES : 3);
 };
 
+#ifdef RT_STATS
+// diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/gpu_stats_probe.py
+__device__ unsigned long long g_stats[16];
+#endif
+
 template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
 __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_simd) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
@@ -543,6 +548,9 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		}
 	};
 
+#ifdef RT_STATS
+	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
+#endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
 	for (;;) {
 		// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
@@ -645,6 +653,16 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 				continue;
 			}
 			const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
+#ifdef RT_STATS
+			if (lane == 0u) {
+				if (!run_light) {
+					st_iters[0] += 1; st_active[0] += n_trace;
+					st_gen += (unsigned long long)__popcll(__ballot(ph == PH_GEN));
+				} else {
+					st_iters[1] += 1; st_active[1] += n_light;
+				}
+			}
+#endif
 			if (!run_light) {
 				if (ph == PH_GEN)
 					do_gen();
@@ -669,6 +687,13 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		}
 	}
 
+#ifdef RT_STATS
+	if (lane == 0u) {
+		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
+		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);
+		atomicAdd(&g_stats[4], st_gen);
+	}
+#endif
 	// ---- SamplerProgress.rays_shot: wave reduction, one atomic per wave ----
 	if (rays_shot != nullptr) {
 		for (int off = 32; off > 0; off >>= 1)
@@ -796,6 +821,19 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 }
 
 // ---- launchers (called from rt_api.cpp) ----
+#ifdef RT_STATS
+extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
+{
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess)
+		return -1;
+	if (reset) {
+		unsigned long long z[16] = {};
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z);
+	}
+	return 0;
+}
+#endif
+
 uint32_t render_block_threads(int feature_set) { return feature_set == 0 ? (uint32_t)KernelShape<Feat<false, false, false, false>>::block : 256u; }
 
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block)

@@ -1,0 +1,16 @@
+"""Schedule statistics from the -DRT_STATS diagnostic build (RT_HIP_LIB=.../librt_hip_stats.so)."""
+import ctypes as C, importlib, sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend"); abi = pkg.abi
+import scenes
+for name in ("rtweekend1", "overshadowed"):
+    ls = scenes.load_ssml(name); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
+    o = abi.default_render_opts(1920, 1080, 64)
+    out = (C.c_ulonglong * 16)()
+    hb.lib().rt_debug_stats(out, 1)
+    img, rays = g.render(cam, o)
+    hb.lib().rt_debug_stats(out, 1)
+    ti, ta, li, la, gen = out[0], out[1], out[2], out[3], out[4]
+    n = 1920 * 1080 * 64
+    print(f"{name}: TRACE iters {ti} avg active {ta/ti:.1f}/64 (gen lanes/iter {gen/ti:.1f}) | LIGHT iters {li} avg active {la/li:.1f}/64 | "
+          f"per sample: trace-lane-steps {ta/n:.2f} light-lane-steps {la/n:.2f}; wave-iters per 64 samples: trace {ti*64/n:.2f} light {li*64/n:.2f}")
