@@ -259,8 +259,10 @@ int rt_scene_set_traversal(rt_scene *scene, int mode);
  *   RT_TUNE_FEATURE_SET   0 spheres-only, 1 + triangles and emissive primitives, 2 every material /
  *                         texture; the library picks the smallest that covers the scene, a caller may
  *                         only raise it
- *   RT_TUNE_SCENE_IN_LDS  1 (default): tiny scenes are staged whole into LDS; 0: read from HBM/L2 */
-typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2 } rt_tuning_key;
+ *   RT_TUNE_SCENE_IN_LDS  1 (default): tiny scenes are staged whole into LDS; 0: read from HBM/L2
+ *   RT_TUNE_SCHEDULE      -1 automatic, 0 coarse (two voted super-phases), 1 fine (every step of the
+ *                         per-lane state machine is voted; implies the pruned walk) */
+typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3 } rt_tuning_key;
 int rt_scene_set_tuning(rt_scene *scene, int key, int value);
 
 /* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----

@@ -25,7 +25,7 @@ RT_SPLIT_SAH, RT_SPLIT_MIDDLE, RT_SPLIT_EQUAL_COUNTS = range(3)
 # enum RenderMethod (samplers/mod.rs:43-47)
 RT_METHOD_NAIVE, RT_METHOD_MIS = range(2)
 RT_LAYOUT_FRAME, RT_LAYOUT_SHARD = range(2)
-RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS = range(3)
+RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS, RT_TUNE_SCHEDULE = range(4)
 
 NO_INDEX = 0xFFFFFFFFFFFFFFFF  # usize::MAX
 

@@ -21,8 +21,8 @@
 namespace rt {
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block);
 uint32_t render_block_threads(int feature_set);
-hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
-hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
+hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
@@ -52,6 +52,15 @@ static int hip_fail(hipError_t e, const char *what)
 			return hip_fail(e_, #expr);     \
 	} while (0)
 
+// Measured crossovers (tests/gpu_crossover_probe.py, tests/gpu_crossover_mesh.py, 1080p):
+//   exhaustive walk + coarse schedule wins up to ~100 primitives, the pruned walk beyond;
+//   the fine schedule (every step voted) wins from a few thousand triangles (10 k: 36 -> 26 ms, 1 M: 189 -> 77 ms)
+//   but only ties on sphere-only scenes even at 16 k (96 vs 106 ms): sphere leaves are cheap, triangle leaves
+//   are long and divergent.
+constexpr uint32_t kPruneAbove = 100;
+constexpr uint32_t kFineAboveTriangles = 2048;
+constexpr uint32_t kFineAboveSpheres = 32768;
+
 struct rt_scene {
 	int device = 0;
 	HostScene host;
@@ -65,6 +74,7 @@ struct rt_scene {
 	uint32_t n_launches = 0;
 	int n_cus = 0;
 	int traversal_mode = -1; // -1 auto, 0 exhaustive (reference order of work), 1 pruned
+	int schedule_mode = -1;  // -1 auto, 0 coarse (two super-phases), 1 fine (every step voted)
 	int feature_set = 2;     // smallest kernel variant covering the scene: 0 spheres-only, 1 simple, 2 full
 	int min_feature_set = 0; // what the scene needs (feature_set may be forced larger for tests)
 	bool scene_lds_allowed = true;
@@ -299,6 +309,11 @@ int rt_scene_set_tuning(rt_scene *s, int key, int value)
 			return fail(RT_ERR_INVALID_ARGUMENT, "feature set must be between the scene's own and 2");
 		s->feature_set = value;
 		return RT_OK;
+	case RT_TUNE_SCHEDULE:
+		if (value < -1 || value > 1)
+			return fail(RT_ERR_INVALID_ARGUMENT, "schedule must be -1, 0 or 1");
+		s->schedule_mode = value;
+		return RT_OK;
 	case RT_TUNE_SCENE_IN_LDS:
 		s->scene_lds_allowed = value != 0;
 		return RT_OK;
@@ -479,7 +494,12 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 
 	// traversal: exhaustive (the reference's own amount of work) for tiny trees where pruning cannot
 	// pay, t-pruned otherwise; both select the same winner (rt_intersect.h)
-	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > 32u : s->traversal_mode == 1;
+	// and how finely the wave votes: measured crossovers on random sphere scenes (tests/gpu_crossover_probe.py)
+	bool prune = s->traversal_mode == -1 ? s->dev.n_prims > kPruneAbove : s->traversal_mode == 1;
+	const bool fine = s->schedule_mode == -1 ? (prune && s->dev.n_prims > (s->dev.has_triangles ? kFineAboveTriangles : kFineAboveSpheres))
+	                                         : s->schedule_mode == 1;
+	if (fine)
+		prune = true;
 	P.prune = prune ? 1 : 0;
 
 	const bool samplable = (s->dev.sky.res_x | s->dev.sky.res_y) != 0u;
@@ -489,19 +509,19 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	// workgroups per CU, the register limit.  Deep trees: the stacks alone are tens of KB and the
 	// sky is a small share of the work, so residency (latency hiding for the node fetches) wins.
 	// Tiny scenes under the coarse schedule: the whole scene rides in LDS too.
-	const bool scene_lds = !prune && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
+	const bool scene_lds = !fine && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
 	P.scene_in_lds = scene_lds ? 1u : 0u;
 	bool sky_lds = false;
 	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, render_block_threads(s->feature_set) / 64u);
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, false, s->feature_set, lds_bytes, &blocks_per_cu));
+	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
 		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, render_block_threads(s->feature_set) / 64u);
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
-		    render_occupancy(o->render_method, prune, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
+		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
 		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
 			sky_lds = true;
 			lds_bytes = lds_with;
@@ -531,7 +551,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	std::memcpy(cam.vertical, camera->vertical, 12);
 
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
-	HIP_TRY(launch_render(o->render_method, prune, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
+	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
@@ -726,7 +746,7 @@ static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *ob
 		e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray_desc), hipMemcpyHostToDevice, s->stream);
 	if (e == hipSuccess && object_index)
 		e = hipMemcpyAsync(d_idx, object_index, n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream);
-	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > 32u : s->traversal_mode == 1;
+	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > kPruneAbove : s->traversal_mode == 1;
 	if (e == hipSuccess)
 		e = object_index ? launch_check_hit_index(prune, s->stream, s->dev, d_rays, d_idx, n, d_out)
 		                 : launch_check_hit(prune, s->stream, s->dev, d_rays, n, d_out);

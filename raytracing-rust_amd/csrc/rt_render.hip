@@ -104,14 +104,11 @@ template <class F> struct KernelShape {
 __device__ unsigned long long g_stats[16];
 #endif
 
-template <int METHOD, bool PRUNE, bool SKY_LDS, class F>
+template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
 __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_simd) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
 {
-	// Scheduling granularity follows the tree: the pruned walk is selected for scenes with more than
-	// a few dozen primitives, where one walk is tens to hundreds of steps and each step deserves a vote.
-	constexpr bool FINE = PRUNE;
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
@@ -853,36 +850,42 @@ typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams
 using FeatSpheres = Feat<false, false, false, false>; // spheres, Lambertian/Emit, Solid/Lerp, sky is the only light (rtweekend1)
 using FeatSimple = Feat<true, true, false, false>;    // + triangles and emissive primitives (overshadowed, the synthetic meshes)
 
-template <class F> static render_fn pick_render_f(int method, bool prune, bool sky_lds)
+template <class F> static render_fn pick_render_f(int method, bool prune, bool fine, bool sky_lds)
 {
-#define RT_PICK(M, P, L) \
-	if (method == M && prune == P && sky_lds == L) \
-		return render_kernel<M, P, L, F>;
-	RT_PICK(0, false, false)
-	RT_PICK(0, true, false)
-	RT_PICK(1, false, false)
-	RT_PICK(1, false, true)
-	RT_PICK(1, true, false)
-	RT_PICK(1, true, true)
+#define RT_PICK(M, P, G, L) \
+	if (method == M && prune == P && fine == G && sky_lds == L) \
+		return render_kernel<M, P, G, L, F>;
+	// (prune, fine): exhaustive+coarse for tiny trees, pruned+coarse for small ones, pruned+fine for big ones
+	RT_PICK(0, false, false, false)
+	RT_PICK(0, true, false, false)
+	RT_PICK(0, true, true, false)
+	RT_PICK(1, false, false, false)
+	RT_PICK(1, false, false, true)
+	RT_PICK(1, true, false, false)
+	RT_PICK(1, true, false, true)
+	RT_PICK(1, true, true, false)
+	RT_PICK(1, true, true, true)
 #undef RT_PICK
 	return nullptr;
 }
 
 // feature_set: 0 spheres-only, 1 simple, 2 full
-static render_fn pick_render(int method, bool prune, bool sky_lds, int feature_set)
+static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, int feature_set)
 {
 	if (method == 0)
 		sky_lds = false; // the naive integrator never touches the sky tables
+	if (fine)
+		prune = true; // the fine schedule is only built with the pruned walk
 	if (feature_set == 0)
-		return pick_render_f<FeatSpheres>(method, prune, sky_lds);
+		return pick_render_f<FeatSpheres>(method, prune, fine, sky_lds);
 	if (feature_set == 1)
-		return pick_render_f<FeatSimple>(method, prune, sky_lds);
-	return pick_render_f<FeatFull>(method, prune, sky_lds);
+		return pick_render_f<FeatSimple>(method, prune, fine, sky_lds);
+	return pick_render_f<FeatFull>(method, prune, fine, sky_lds);
 }
 
-hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu)
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu)
 {
-	render_fn fn = pick_render(method, prune, sky_lds, feature_set);
+	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -891,11 +894,11 @@ hipError_t render_occupancy(int method, bool prune, bool sky_lds, int feature_se
 	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set), lds_bytes);
 }
 
-hipError_t launch_render(int method, bool prune, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
+hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter)
 {
-	render_fn fn = pick_render(method, prune, sky_lds, feature_set);
+	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
 	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
