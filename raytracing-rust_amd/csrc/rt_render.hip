@@ -57,8 +57,12 @@ enum : int {
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
+#ifndef RT_DRAIN_LANES
+#define RT_DRAIN_LANES 6
+#endif
+constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase runs once this many lanes wait for it
 #ifndef RT_NODE_STEPS_PER_VOTE
-#define RT_NODE_STEPS_PER_VOTE 8
+#define RT_NODE_STEPS_PER_VOTE 16
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_SPHERES_WAVES
@@ -101,7 +105,7 @@ template <class F> struct KernelShape {
 
 #ifdef RT_STATS
 // diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/gpu_stats_probe.py
-__device__ unsigned long long g_stats[16];
+__device__ unsigned long long g_stats[32];
 #endif
 
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 
 #ifdef RT_STATS
 	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
+	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
 	for (;;) {
@@ -600,14 +605,35 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		if (FINE) {
 			// ---- big trees: every step is its own phase; run the one most lanes wait for
 			// (ties: the later pipeline stage) ----
+			// NODE steps are the bulk of the work (a walk is tens to hundreds of them, 8 per vote), every other
+			// phase is short.  So the short phases are DRAINED eagerly -- any of them runs as soon as
+			// kDrainLanes lanes wait for it, later pipeline stages first -- which keeps lanes flowing back
+			// into NODE and NODE's occupancy high; NODE runs otherwise; when no NODE lane is left the fullest
+			// remaining phase runs.  (Pure arg-max left NODE at 32/64 lanes on 1 M triangles.)
+			uint32_t cnt[PH_COUNT];
+#pragma unroll
+			for (int k = 0; k < PH_COUNT; ++k)
+				cnt[k] = (uint32_t)__popcll(__ballot(ph == k));
 			int run = -1;
 			uint32_t best_n = 0;
 #pragma unroll
-			for (int k = 0; k < PH_COUNT; ++k) {
-				const uint32_t c = (uint32_t)__popcll(__ballot(ph == k));
-				if (c >= best_n && c > 0u) {
-					best_n = c;
+			for (int k = PH_COUNT - 1; k >= 0; --k) {
+				if (k != PH_NODE && run < 0 && cnt[k] >= kDrainLanes) {
 					run = k;
+					best_n = cnt[k];
+				}
+			}
+			if (run < 0 && cnt[PH_NODE] > 0u) {
+				run = PH_NODE;
+				best_n = cnt[PH_NODE];
+			}
+			if (run < 0) {
+#pragma unroll
+				for (int k = 0; k < PH_COUNT; ++k) {
+					if (cnt[k] >= best_n && cnt[k] > 0u) {
+						best_n = cnt[k];
+						run = k;
+					}
 				}
 			}
 			if (run < 0) {
@@ -615,6 +641,12 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 					break; // every lane is PH_DONE
 				continue;  // only edge-tile padding was handed out: ask again
 			}
+#ifdef RT_STATS
+			if (lane == 0u) {
+				st_fine_iters[run] += 1;
+				st_fine_active[run] += best_n;
+			}
+#endif
 			if (run == PH_NODE) {
 				// a few node steps per vote: a walk is tens to hundreds of them and the vote is not free
 #pragma unroll 1
@@ -689,6 +721,10 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
 		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);
 		atomicAdd(&g_stats[4], st_gen);
+		for (int k = 0; k < PH_COUNT; ++k) {
+			atomicAdd(&g_stats[5 + k], st_fine_iters[k]);
+			atomicAdd(&g_stats[5 + PH_COUNT + k], st_fine_active[k]);
+		}
 	}
 #endif
 	// ---- SamplerProgress.rays_shot: wave reduction, one atomic per wave ----
@@ -824,7 +860,7 @@ extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess)
 		return -1;
 	if (reset) {
-		unsigned long long z[16] = {};
+		unsigned long long z[32] = {};
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z);
 	}
 	return 0;
