@@ -119,3 +119,63 @@ def all_materials(seed=3, sampler_res=(32, 16)):
 
 ALL_MATERIALS_CAMERA = dict(origin=(0.0, 1.5, 6.0), lookat=(0.0, 0.6, 0.0), vup=(0.0, 1.0, 0.0), fov=40.0,
                             aspect_ratio=float(np.float32(16.0) / np.float32(9.0)), aperture=0.0, focus_dist=10.0)
+
+
+def icosphere(subdivisions):
+    """unit icosphere: vertices [n,3] f32 (also its smooth normals), triangles [m,3] u32 -- a closed mesh whose
+    triangles share every edge and vertex (the watertight / tie-breaking cases random soup never produces)"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for (a, b, c) in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, dtype=np.float32), np.array(f, dtype=np.uint32)
+
+
+def structured_meshes(subdivisions=4, grid=96, sampler_res=(50, 25)):
+    """a smooth-shaded icosphere (emissive) over a rolling heightfield of grid x grid quads (Lambertian) plus a
+    diffuse icosphere: closed meshes with shared edges, per-vertex normals, and a mesh light"""
+    sc = SceneDescription()
+    grey = sc.lambertian(sc.solid((0.6, 0.6, 0.55)), 0.8)
+    red = sc.lambertian(sc.solid((0.8, 0.3, 0.25)), 0.9)
+    glow = sc.emissive(sc.solid((1.0, 0.9, 0.7)), 4.0)
+    # heightfield on the xz plane
+    xs = np.linspace(-6, 6, grid + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    Y = (0.35 * np.sin(1.3 * X) * np.cos(0.9 * Z) - 0.2).astype(np.float32)
+    verts = np.stack([X, Y, Z], axis=-1).reshape(-1, 3).astype(np.float32)
+    dydx = 0.35 * 1.3 * np.cos(1.3 * X) * np.cos(0.9 * Z)
+    dydz = -0.35 * 0.9 * np.sin(1.3 * X) * np.sin(0.9 * Z)
+    nrm = np.stack([-dydx, np.ones_like(dydx), -dydz], axis=-1).reshape(-1, 3)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    idx = np.arange((grid + 1) * (grid + 1), dtype=np.uint32).reshape(grid + 1, grid + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+    m = sc.mesh(verts, nrm)
+    sc.mesh_triangles_bulk(m, tris, tris, np.full(len(tris), grey, np.uint32))
+    v, f = icosphere(subdivisions)
+    for (centre, radius, mat) in (((0.0, 0.9, 0.0), 0.8, red), ((2.2, 2.4, -1.0), 0.5, glow)):
+        mv = (v * np.float32(radius) + np.float32(centre)).astype(np.float32)
+        mm = sc.mesh(mv, v)
+        sc.mesh_triangles_bulk(mm, f, f, np.full(len(f), mat, np.uint32))
+    sc.set_sky(sc.lerp((0.5, 0.7, 1.0), (1.0, 1.0, 1.0)), sampler_res)
+    return sc
+
+
+STRUCTURED_CAMERA = dict(origin=(5.0, 3.0, 6.0), lookat=(0.0, 0.6, 0.0), vup=(0.0, 1.0, 0.0), fov=45.0,
+                         aspect_ratio=float(np.float32(16.0) / np.float32(9.0)), aperture=0.0, focus_dist=10.0)

@@ -73,6 +73,7 @@ def test_golden_images(O, golden_dir):
         "all_materials": (scenes.all_materials(), scenes.ALL_MATERIALS_CAMERA, 8),
         "mesh2000": (scenes.random_triangle_mesh(2000, seed=42, extent=3.0, edge=0.5, emissive_every=100, sampler_res=(20, 10)),
                      scenes.MESH_CAMERA | {"origin": (0.0, -9.0, 0.0)}, 8),
+        "structured": (scenes.structured_meshes(3, 32, (20, 10)), scenes.STRUCTURED_CAMERA, 8),
     }
     for name, (sc, cam_params, spp) in cases.items():
         s = O.Scene(sc)
