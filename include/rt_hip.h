@@ -291,10 +291,11 @@ int rt_last_kernel_ms(rt_scene *scene, float *ms, uint32_t *n_launches);
 
 /* ---- output stage, the step right after the path: crates/output/src/lib.rs:74-113 save_data_to_image.
  * Host-side (no GPU needed).  rt_output_rgb8 is the reference's pixel conversion
- * `(val.powf(1.0 / gamma) * 255.999) as u8` (`as u8` saturates, NaN -> 0); rt_output_save writes
- * width*height RGB8 pixels as .png (stored deflate blocks) or .ppm, chosen by the extension the way
- * save_data_to_image does; other extensions the reference accepts (jpg, tiff, bmp, exr) return
- * RT_ERR_UNSUPPORTED. ---- */
+ * `(val.powf(1.0 / gamma) * 255.999) as u8` (`as u8` saturates, NaN -> 0); rt_output_save dispatches on
+ * the extension the way save_data_to_image does: .png (stored deflate blocks), .ppm, .bmp (24-bit) and
+ * .tiff (one uncompressed strip) receive those RGB8 pixels; .exr receives the float image itself with gamma
+ * ignored (lib.rs:99-106), as an uncompressed scanline file with FLOAT channels B, G, R.  jpg/jpeg, which the
+ * reference hands to the image crate, and unknown extensions return RT_ERR_UNSUPPORTED. ---- */
 int rt_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *out);
 int rt_output_save(const char *filename, const float *rgb, uint32_t width, uint32_t height, float gamma);
 

@@ -631,6 +631,14 @@ void put_be32(std::vector<uint8_t> &v, uint32_t x)
 {
 	v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
 }
+void put_le32(std::vector<uint8_t> &v, uint32_t x)
+{
+	v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 24));
+}
+void put_str0(std::vector<uint8_t> &v, const char *s)
+{
+	v.insert(v.end(), s, s + std::strlen(s) + 1);
+}
 void png_chunk(std::vector<uint8_t> &png, const char type[4], const std::vector<uint8_t> &data)
 {
 	put_be32(png, (uint32_t)data.size());
@@ -667,51 +675,144 @@ int rt_output_save(const char *filename, const float *rgb, uint32_t width, uint3
 		return fail(RT_ERR_INVALID_ARGUMENT, "Invalid filename: exactly one '.' expected");
 	const std::string ext = name.substr(dot + 1);
 	const uint64_t n = (uint64_t)width * height * 3;
-	std::vector<uint8_t> px(n);
-	rt_output_rgb8(rgb, n, gamma, px.data());
 	std::vector<uint8_t> file;
-	if (ext == "ppm") {
-		char header[64];
-		const int len = std::snprintf(header, sizeof header, "P6\n%u %u\n255\n", width, height);
-		file.assign(header, header + len);
-		file.insert(file.end(), px.begin(), px.end());
-	} else if (ext == "png") {
-		static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-		file.assign(sig, sig + 8);
-		std::vector<uint8_t> ihdr;
-		put_be32(ihdr, width);
-		put_be32(ihdr, height);
-		const uint8_t rest[5] = {8, 2, 0, 0, 0}; // 8 bits, RGB
-		ihdr.insert(ihdr.end(), rest, rest + 5);
-		png_chunk(file, "IHDR", ihdr);
-		// scanlines with filter byte 0, wrapped in zlib "stored" blocks
-		std::vector<uint8_t> raw;
-		raw.reserve((size_t)height * (width * 3 + 1));
+	if (ext == "exr") {
+		// "gamma is ignored because of exr" (lib.rs:99-106): the float image itself, as an uncompressed
+		// scanline OpenEXR file with FLOAT channels B, G, R
+		static const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+		file.assign(magic, magic + 8);
+		auto attr = [&](const char *aname, const char *type, const std::vector<uint8_t> &value) {
+			put_str0(file, aname);
+			put_str0(file, type);
+			put_le32(file, (uint32_t)value.size());
+			file.insert(file.end(), value.begin(), value.end());
+		};
+		std::vector<uint8_t> v;
+		for (const char *ch : {"B", "G", "R"}) {
+			put_str0(v, ch);
+			put_le32(v, 2); // FLOAT
+			put_le32(v, 0); // pLinear + 3 reserved bytes
+			put_le32(v, 1); // xSampling
+			put_le32(v, 1); // ySampling
+		}
+		v.push_back(0);
+		attr("channels", "chlist", v);
+		attr("compression", "compression", {0});
+		v.clear();
+		put_le32(v, 0); put_le32(v, 0); put_le32(v, width - 1); put_le32(v, height - 1);
+		attr("dataWindow", "box2i", v);
+		attr("displayWindow", "box2i", v);
+		attr("lineOrder", "lineOrder", {0});
+		v.clear();
+		put_le32(v, 0x3F800000u);
+		attr("pixelAspectRatio", "float", v);
+		attr("screenWindowWidth", "float", v);
+		v.clear();
+		put_le32(v, 0); put_le32(v, 0);
+		attr("screenWindowCenter", "v2f", v);
+		file.push_back(0);
+		const uint64_t row_bytes = (uint64_t)width * 12;
+		const uint64_t first = file.size() + (uint64_t)height * 8;
 		for (uint32_t y = 0; y < height; ++y) {
-			raw.push_back(0);
-			raw.insert(raw.end(), px.begin() + (size_t)y * width * 3, px.begin() + (size_t)(y + 1) * width * 3);
+			const uint64_t off = first + (uint64_t)y * (8 + row_bytes);
+			put_le32(file, (uint32_t)off);
+			put_le32(file, (uint32_t)(off >> 32));
 		}
-		std::vector<uint8_t> z;
-		z.push_back(0x78);
-		z.push_back(0x01);
-		uint32_t a = 1, b = 0; // adler32
-		for (size_t pos = 0; pos < raw.size();) {
-			const size_t len = std::min<size_t>(65535, raw.size() - pos);
-			z.push_back(pos + len == raw.size() ? 1 : 0);
-			z.push_back((uint8_t)(len & 0xFF)); z.push_back((uint8_t)(len >> 8));
-			z.push_back((uint8_t)(~len & 0xFF)); z.push_back((uint8_t)((~len >> 8) & 0xFF));
-			z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
-			for (size_t i = pos; i < pos + len; ++i) {
-				a = (a + raw[i]) % 65521u;
-				b = (b + a) % 65521u;
+		file.reserve(file.size() + (size_t)height * (8 + row_bytes));
+		for (uint32_t y = 0; y < height; ++y) {
+			put_le32(file, y);
+			put_le32(file, (uint32_t)row_bytes);
+			for (int c = 2; c >= 0; --c) // B, G, R planes of the scanline
+				for (uint32_t x = 0; x < width; ++x) {
+					uint32_t bits;
+					std::memcpy(&bits, &rgb[((size_t)y * width + x) * 3 + c], 4);
+					put_le32(file, bits);
+				}
+		}
+	} else if (ext == "ppm" || ext == "png" || ext == "bmp" || ext == "tiff") {
+		std::vector<uint8_t> px(n);
+		rt_output_rgb8(rgb, n, gamma, px.data());
+		if (ext == "ppm") {
+			char header[64];
+			const int len = std::snprintf(header, sizeof header, "P6\n%u %u\n255\n", width, height);
+			file.assign(header, header + len);
+			file.insert(file.end(), px.begin(), px.end());
+		} else if (ext == "bmp") {
+			// 24-bit BI_RGB, bottom-up rows of B,G,R padded to 4 bytes
+			const uint32_t stride = (width * 3 + 3) & ~3u;
+			const uint32_t size = 54 + stride * height;
+			file.push_back('B'); file.push_back('M');
+			put_le32(file, size); put_le32(file, 0); put_le32(file, 54);
+			put_le32(file, 40); put_le32(file, width); put_le32(file, height);
+			put_le32(file, 1u | (24u << 16)); // planes, bits per pixel
+			put_le32(file, 0); put_le32(file, stride * height);
+			put_le32(file, 2835); put_le32(file, 2835); put_le32(file, 0); put_le32(file, 0);
+			file.resize(size, 0);
+			for (uint32_t y = 0; y < height; ++y) {
+				uint8_t *row = file.data() + 54 + (size_t)(height - 1 - y) * stride;
+				for (uint32_t x = 0; x < width; ++x)
+					for (int c = 0; c < 3; ++c)
+						row[x * 3 + c] = px[((size_t)y * width + x) * 3 + (2 - c)];
 			}
-			pos += len;
+		} else if (ext == "tiff") {
+			// little-endian baseline TIFF: one uncompressed RGB strip, then the IFD
+			const uint32_t strip = 8, bits_at = strip + (uint32_t)n, ifd_at = (bits_at + 6 + 1) & ~1u;
+			file.push_back('I'); file.push_back('I'); file.push_back(42); file.push_back(0);
+			put_le32(file, ifd_at);
+			file.insert(file.end(), px.begin(), px.end());
+			for (int c = 0; c < 3; ++c) { file.push_back(8); file.push_back(0); }
+			file.resize(ifd_at, 0);
+			struct Tag { uint16_t id, type; uint32_t count, value; };
+			const Tag tags[] = {{256, 4, 1, width}, {257, 4, 1, height}, {258, 3, 3, bits_at}, {259, 3, 1, 1}, {262, 3, 1, 2},
+			                    {273, 4, 1, strip}, {277, 3, 1, 3}, {278, 4, 1, height}, {279, 4, 1, (uint32_t)n}, {284, 3, 1, 1}};
+			const uint16_t n_tags = sizeof tags / sizeof tags[0];
+			file.push_back((uint8_t)n_tags); file.push_back(0);
+			for (const Tag &t : tags) {
+				file.push_back((uint8_t)t.id); file.push_back((uint8_t)(t.id >> 8));
+				file.push_back((uint8_t)t.type); file.push_back(0);
+				put_le32(file, t.count);
+				put_le32(file, t.value); // SHORT values sit in the low half of the little-endian field
+			}
+			put_le32(file, 0);
+		} else {
+			static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+			file.assign(sig, sig + 8);
+			std::vector<uint8_t> ihdr;
+			put_be32(ihdr, width);
+			put_be32(ihdr, height);
+			const uint8_t rest[5] = {8, 2, 0, 0, 0}; // 8 bits, RGB
+			ihdr.insert(ihdr.end(), rest, rest + 5);
+			png_chunk(file, "IHDR", ihdr);
+			// scanlines with filter byte 0, wrapped in zlib "stored" blocks
+			std::vector<uint8_t> raw;
+			raw.reserve((size_t)height * (width * 3 + 1));
+			for (uint32_t y = 0; y < height; ++y) {
+				raw.push_back(0);
+				raw.insert(raw.end(), px.begin() + (size_t)y * width * 3, px.begin() + (size_t)(y + 1) * width * 3);
+			}
+			std::vector<uint8_t> z;
+			z.push_back(0x78);
+			z.push_back(0x01);
+			uint32_t a = 1, b = 0; // adler32
+			for (size_t pos = 0; pos < raw.size();) {
+				const size_t len = std::min<size_t>(65535, raw.size() - pos);
+				z.push_back(pos + len == raw.size() ? 1 : 0);
+				z.push_back((uint8_t)(len & 0xFF)); z.push_back((uint8_t)(len >> 8));
+				z.push_back((uint8_t)(~len & 0xFF)); z.push_back((uint8_t)((~len >> 8) & 0xFF));
+				z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+				for (size_t i = pos; i < pos + len; ++i) {
+					a = (a + raw[i]) % 65521u;
+					b = (b + a) % 65521u;
+				}
+				pos += len;
+			}
+			put_be32(z, (b << 16) | a);
+			png_chunk(file, "IDAT", z);
+			png_chunk(file, "IEND", {});
 		}
-		put_be32(z, (b << 16) | a);
-		png_chunk(file, "IDAT", z);
-		png_chunk(file, "IEND", {});
 	} else {
-		return fail(RT_ERR_UNSUPPORTED, "Unable to save file: only .png and .ppm are implemented (unknown or unsupported filetype ." + ext + ")");
+		// the reference also hands jpg/jpeg to the image crate; no JPEG encoder here
+		return fail(RT_ERR_UNSUPPORTED, "Unable to save file: (unknown or unsupported filetype ." + ext + ")");
 	}
 	FILE *f = std::fopen(filename, "wb");
 	if (!f)

@@ -247,7 +247,7 @@ def output_rgb8(image, gamma=2.2):
 
 
 def save_image(filename, image, gamma=2.2):
-    """save_data_to_image (crates/output/src/lib.rs:74-113): .png or .ppm by extension."""
+    """save_data_to_image (crates/output/src/lib.rs:74-113): .png .ppm .bmp .tiff (RGB8 after gamma) or .exr (floats) by extension."""
     a = np.ascontiguousarray(image, dtype=np.float32)
     h, w, _ = a.shape
     _check(lib().rt_output_save(filename.encode(), _p(a, C.c_float), C.c_uint32(w), C.c_uint32(h), C.c_float(gamma)))

@@ -57,9 +57,57 @@ def test_png_and_ppm_round_trip(hb, tmp_path):
         assert data.startswith(header) and np.array_equal(np.frombuffer(data[len(header):], np.uint8).reshape(h, w, 3), want)
 
 
+def _read_exr(path):
+    """minimal OpenEXR reader: single-part scanline file, no compression, FLOAT channels"""
+    d = open(path, "rb").read()
+    assert d[:4] == b"\x76\x2f\x31\x01" and struct.unpack("<I", d[4:8])[0] == 2
+    pos, attrs = 8, {}
+    while d[pos] != 0:
+        e = d.index(b"\0", pos); name = d[pos:e].decode(); pos = e + 1
+        e = d.index(b"\0", pos); typ = d[pos:e].decode(); pos = e + 1
+        size, = struct.unpack("<i", d[pos:pos + 4]); pos += 4
+        attrs[name] = (typ, d[pos:pos + size]); pos += size
+    pos += 1
+    for required in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
+                     "screenWindowCenter", "screenWindowWidth"):
+        assert required in attrs, required
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    names, c, p = [], attrs["channels"][1], 0
+    while c[p] != 0:
+        e = c.index(b"\0", p); names.append(c[p:e].decode()); p = e + 1
+        assert struct.unpack("<iB3xii", c[p:p + 16]) == (2, 0, 1, 1); p += 16
+    assert names == sorted(names) == ["B", "G", "R"]
+    offsets = struct.unpack(f"<{h}Q", d[pos:pos + 8 * h])
+    img = np.zeros((h, w, 3), dtype=np.float32)
+    for y, off in enumerate(offsets):
+        yy, size = struct.unpack("<ii", d[off:off + 8])
+        assert yy == y and size == w * 12
+        planes = np.frombuffer(d[off + 8:off + 8 + size], dtype="<f4").reshape(3, w)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = planes[0], planes[1], planes[2]
+    assert offsets[-1] + 8 + w * 12 == len(d)
+    return img
+
+
+def test_exr_bmp_tiff(hb, tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.uniform(0, 4, (37, 53, 3)).astype(np.float32)  # odd width: BMP row padding
+    img[3, 5] = (np.inf, 1e-30, 0.0)
+    hb.save_image(str(tmp_path / "a.exr"), img, 2.2)
+    assert _read_exr(str(tmp_path / "a.exr")).tobytes() == img.tobytes()  # gamma ignored, floats untouched
+    want = hb.output_rgb8(img, 2.2)
+    Image = pytest.importorskip("PIL.Image")
+    for ext in ("bmp", "tiff", "png"):
+        hb.save_image(str(tmp_path / f"a.{ext}"), img, 2.2)
+        with Image.open(tmp_path / f"a.{ext}") as im:
+            assert im.mode == "RGB" and im.size == (53, 37)
+            assert np.array_equal(np.asarray(im), want), ext
+
+
 def test_filename_rules(hb, tmp_path):
     img = np.zeros((2, 2, 3), dtype=np.float32)
-    for bad, code in (("noext", abi.RT_ERR_INVALID_ARGUMENT), ("a.b.png", abi.RT_ERR_INVALID_ARGUMENT), ("x.exr", abi.RT_ERR_UNSUPPORTED)):
+    for bad, code in (("noext", abi.RT_ERR_INVALID_ARGUMENT), ("a.b.png", abi.RT_ERR_INVALID_ARGUMENT), ("x.jpg", abi.RT_ERR_UNSUPPORTED), ("x.gif", abi.RT_ERR_UNSUPPORTED)):
         with pytest.raises(hb.RtHipError) as e:
             hb.save_image(bad, img)  # like the reference: exactly one '.', dispatch on the extension
         assert e.value.code == code
