@@ -271,8 +271,16 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	
 	};
 
+#ifdef RT_STATS
+	unsigned long long st_lane_nodes = 0, st_lane_prims = 0, st_lane_maxsp = 0;
+#endif
 	// NODE -- one inner-node step: Bvh::get_intersection_candidates' loop body (mod.rs:203-221)
 	auto do_node = [&]() {
+#ifdef RT_STATS
+		st_lane_nodes += 1;
+		if ((unsigned long long)sp > st_lane_maxsp)
+			st_lane_maxsp = (unsigned long long)sp;
+#endif
 		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
 		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
 		after_step();
@@ -287,6 +295,9 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 		for (uint32_t slot = first; slot < first + count; ++slot) {
 			if (any_hit && slot == PL.skip)
 				continue;
+#ifdef RT_STATS
+			st_lane_prims += 1;
+#endif
 			const PrimGeom g = load_prim<F>(S, slot);
 			float t;
 			if (prim_t<F>(g, ray, t) && t > 0.0f) {
@@ -717,6 +728,9 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	}
 
 #ifdef RT_STATS
+	atomicAdd(&g_stats[20], st_lane_nodes); // lane-level node steps and primitive tests of the fine schedule
+	atomicAdd(&g_stats[21], st_lane_prims);
+	atomicMax(&g_stats[22], st_lane_maxsp);
 	if (lane == 0u) {
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
 		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);

@@ -35,6 +35,12 @@ def main():
             r = count(name, ls.scene, ls.camera_params, 1920, 1080, 4, method, 1024)
             out[f"{name}_1920x1080_{mname}"] = r
             print(name, mname, round(r["bytes_per_sample"], 2), {k: round(v, 3) for k, v in r["per_sample"].items()})
+    # cfg4: the synthetic 1 M-triangle mesh (BASELINE configs[3]); one pass at quarter resolution is enough
+    mesh = scenes.random_triangle_mesh(1000000, seed=42, extent=10.0)
+    for method, mname in ((abi.RT_METHOD_MIS, "mis"), (abi.RT_METHOD_NAIVE, "naive")):
+        r = count("mesh1m", mesh, scenes.MESH_CAMERA, 960, 540, 1, method, 256)
+        out[f"mesh1m_1920x1080_{mname}"] = r
+        print("mesh1m", mname, round(r["bytes_per_sample"], 2), {k: round(v, 3) for k, v in r["per_sample"].items()})
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", "algorithmic_bytes.json"), "w"), indent=1, sort_keys=True)
 

@@ -8,6 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CMD="python3 $R/$*"
+echo "rocprofv3 --kernel-trace --stats -- python3 $* (stats); rocprofv3 --pmc <set> --kernel-trace -- python3 $* (one run per set)" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.out 2> $OUT/trace.err || exit 1
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \

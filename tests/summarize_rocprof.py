@@ -9,7 +9,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# summarize_rocprof.py <tag> [samples per launch] [key in hbm_traffic.json]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+samples_per_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 1920 * 1080 * 1024
+traffic_key = sys.argv[3] if len(sys.argv) > 3 else "rtweekend1_1920x1080x1024_mis"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -46,8 +49,10 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 c = counters
 summary = {
     "tag": tag,
-    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (stats); "
+    "command": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else
+               "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (stats); "
                "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (one run per set)",
+    "samples_per_launch": samples_per_launch,
     "kernel": render["Name"],
     "kernel_calls": int(render["Calls"]),
     "kernel_avg_ms": float(render["AverageNs"]) / 1e6,
@@ -69,7 +74,7 @@ if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
                                     "wait_any": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                                     "wait_inst_any": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]}
 if "SQ_INSTS_VALU" in c:
-    samples = 1920 * 1080 * 1024
+    samples = samples_per_launch
     summary["valu_wave_instructions_per_sample"] = c["SQ_INSTS_VALU"] / samples
     summary["valu_wave_instructions_per_second"] = c["SQ_INSTS_VALU"] / (summary["kernel_avg_ms"] * 1e-3)
     summary["valu_issue_peak_per_second"] = 256 * 4 * 2.4e9 / 2  # 1024 SIMD-32 x one wave64 VALU op per 2 cycles
@@ -81,6 +86,6 @@ json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 tp = os.path.join(dst, "hbm_traffic.json")
 traffic = json.load(open(tp)) if os.path.exists(tp) else {}
 if "hbm_bytes_per_launch" in summary:
-    traffic["rtweekend1_1920x1080x1024_mis"] = {"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc.json"}
+    traffic[traffic_key] = {"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc.json"}
     json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k not in ("counters_per_launch", "command")}, indent=1))
