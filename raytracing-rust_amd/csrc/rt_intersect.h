@@ -333,18 +333,34 @@ __device__ __forceinline__ bool beyond(float t_entry, float t_best, const float 
 // entered beyond t_limit (PRUNE only).
 template <bool PRUNE>
 __device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid,
-                                            float t_limit)
+                                            float t_limit
+#ifdef RT_STATS
+                                            , unsigned long long *g_walk_stats = nullptr // diagnostic build: dead-visit counters
+#endif
+)
 {
 	const NodeView n = load_node(S, node);
 	float t0, t1;
 	bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 	bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+#ifdef RT_STATS
+	const bool g0 = h0, g1 = h1;
+#endif
 	if (PRUNE && limit_valid) {
 		if (h0 && beyond(t0, t_limit, n.c0min, n.c0max))
 			h0 = false;
 		if (h1 && beyond(t1, t_limit, n.c1min, n.c1max))
 			h1 = false;
 	}
+#ifdef RT_STATS
+	if (g_walk_stats && !h0 && !h1) {
+		g_walk_stats[0] += 1;             // dead visit: nothing to descend into
+		if (g0 || g1)
+			g_walk_stats[1] += 1;         // ... and at least one child was hit but pruned
+		if ((g0 && !g1 && !h0) || (g1 && !g0 && !h1) || (g0 && g1))
+			g_walk_stats[2] += 1;         // ... every geometrically hit child was pruned
+	}
+#endif
 	if (h0 && h1) {
 		uint32_t near = n.c0, far = n.c1;
 		if (PRUNE && t1 < t0) { // nearer child first, so the farther one can be pruned later

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	};
 
 #ifdef RT_STATS
-	unsigned long long st_lane_nodes = 0, st_lane_prims = 0, st_lane_maxsp = 0;
+	unsigned long long st_lane_nodes = 0, st_lane_prims = 0, st_lane_maxsp = 0, st_lane_dead[3] = {0, 0, 0};
 #endif
 	// NODE -- one inner-node step: Bvh::get_intersection_candidates' loop body (mod.rs:203-221)
 	auto do_node = [&]() {
@@ -282,7 +282,11 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 			st_lane_maxsp = (unsigned long long)sp;
 #endif
 		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
+#ifdef RT_STATS
+		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t, st_lane_dead);
+#else
 		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
+#endif
 		after_step();
 	
 	};
@@ -731,6 +735,9 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	atomicAdd(&g_stats[20], st_lane_nodes); // lane-level node steps and primitive tests of the fine schedule
 	atomicAdd(&g_stats[21], st_lane_prims);
 	atomicMax(&g_stats[22], st_lane_maxsp);
+	atomicAdd(&g_stats[23], st_lane_dead[0]); // node visits that led nowhere / had a hit child pruned / had every hit child pruned
+	atomicAdd(&g_stats[24], st_lane_dead[1]);
+	atomicAdd(&g_stats[25], st_lane_dead[2]);
 	if (lane == 0u) {
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
 		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);

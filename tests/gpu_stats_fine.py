@@ -17,3 +17,4 @@ for method in (0, 1):
         if it: print(f"   {names[k]:9s} iters {it:10d} ({100*it/tot:5.1f}%)  avg lanes {act/it:5.1f}/64")
     n = 1920 * 1080 * 8
     print(f"   lane node steps {out[20]} ({out[20]/n:.1f}/sample)  primitive tests {out[21]} ({out[21]/n:.2f}/sample)  max stack {out[22]}")
+    print(f"   dead node visits {out[23]/max(1,out[20]):.3f} of all; with a pruned hit child {out[24]/max(1,out[20]):.3f}; all hit children pruned {out[25]/max(1,out[20]):.3f}")
