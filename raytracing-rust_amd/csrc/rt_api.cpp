@@ -26,6 +26,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
                          unsigned long long *rays_shot, uint32_t *work_counter);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
+hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
@@ -444,10 +445,8 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	HIP_TRY(hipSetDevice(s->device));
 	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 	if (g.n_work == 0) { // this shard owns no tile (more shards than tiles)
-		if (o->output_layout == RT_LAYOUT_FRAME)
-			HIP_TRY(hipMemsetAsync(d_out_rgb, 0, o->width * o->height * 3 * sizeof(float), stream));
-		if (d_rays_shot)
-			HIP_TRY(hipMemsetAsync(d_rays_shot, 0, sizeof(uint64_t), stream));
+		HIP_TRY(launch_reset(stream, s->d_work_counter, reinterpret_cast<unsigned long long *>(d_rays_shot), d_out_rgb,
+		                     o->output_layout == RT_LAYOUT_FRAME ? (size_t)(o->width * o->height * 3) : 0));
 		s->timed = false;
 		return RT_OK;
 	}
@@ -536,13 +535,14 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	if (n_blocks > blocks_needed)
 		n_blocks = blocks_needed ? blocks_needed : 1;
 
-	if (o->output_layout == RT_LAYOUT_FRAME && o->shard_count > 1)
-		HIP_TRY(hipMemsetAsync(d_out_rgb, 0, o->width * o->height * 3 * sizeof(float), stream));
-	if (o->output_layout == RT_LAYOUT_SHARD)
-		HIP_TRY(hipMemsetAsync(d_out_rgb, 0, g.n_work * 3 * sizeof(float), stream));
-	HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
-	if (d_rays_shot)
-		HIP_TRY(hipMemsetAsync(d_rays_shot, 0, sizeof(uint64_t), stream));
+	{ // counters, and the parts of the output no lane will write (other shards' pixels, edge-tile padding)
+		size_t zero_floats = 0;
+		if (o->output_layout == RT_LAYOUT_FRAME && o->shard_count > 1)
+			zero_floats = (size_t)(o->width * o->height * 3);
+		if (o->output_layout == RT_LAYOUT_SHARD)
+			zero_floats = (size_t)(g.n_work * 3);
+		HIP_TRY(launch_reset(stream, s->d_work_counter, reinterpret_cast<unsigned long long *>(d_rays_shot), d_out_rgb, zero_floats));
+	}
 
 	DevCamera cam;
 	std::memcpy(cam.origin, camera->origin, 12);

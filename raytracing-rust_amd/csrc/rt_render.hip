@@ -782,6 +782,33 @@ __global__ __launch_bounds__(256) void combine_chunks_kernel(const DevRenderPara
 	out[3u * o + 2u] = acc.z / (float)P.spp;
 }
 
+// Zeroes the per-launch counters (and, for packed / multi-shard outputs, the output buffer) with a kernel
+// instead of hipMemsetAsync: memset nodes of a captured HIP graph were observed to replay an 8-byte
+// memset with a garbage fill value on ROCm 7.2 (tests/test_gpu_parity.py::test_render_device_is_graph_capturable),
+// and one launch replaces up to three.
+__global__ __launch_bounds__(256) void reset_kernel(uint32_t *__restrict__ work_counter, unsigned long long *__restrict__ rays_shot,
+                                                    float *__restrict__ out, size_t n_out_floats)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) {
+		*work_counter = 0u;
+		if (rays_shot)
+			*rays_shot = 0ull;
+	}
+	for (size_t k = i; k < n_out_floats; k += (size_t)gridDim.x * blockDim.x)
+		out[k] = 0.0f;
+}
+hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats)
+{
+	size_t blocks = (n_out_floats + 255) / 256;
+	if (blocks < 1)
+		blocks = 1;
+	if (blocks > 4096)
+		blocks = 4096;
+	hipLaunchKernelGGL(reset_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, work_counter, rays_shot, out, n_out_floats);
+	return hipGetLastError();
+}
+
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out)
 {
 	hipLaunchKernelGGL(combine_chunks_kernel, dim3((P.n_work + 255u) / 256u), dim3(256), 0, stream, P, partial, out);

@@ -6,7 +6,7 @@ import scenes
 for name in ("rtweekend1", "overshadowed"):
     ls = scenes.load_ssml(name); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
     o = abi.default_render_opts(1920, 1080, 64)
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 32)()
     hb.lib().rt_debug_stats(out, 1)
     img, rays = g.render(cam, o)
     hb.lib().rt_debug_stats(out, 1)
