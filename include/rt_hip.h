@@ -284,6 +284,27 @@ int rt_render_output_floats(const rt_render_opts *opts, uint64_t *n_floats);
 /* pixel indices (y*width+x) of the shard's pixels in the order RT_LAYOUT_SHARD packs them */
 int rt_shard_pixel_order(const rt_render_opts *opts, uint64_t *out, uint64_t capacity);
 
+/* ---- Sampler::sample_image with its presentation callback (samplers/mod.rs:7-20,
+ * samplers/random_sampler.rs:10-99), batched.  The reference renders pass i into one of two
+ * SamplerProgress buffers, then hands the OTHER buffer (pass i-1) to the callback
+ * `F: Fn(&mut T, &SamplerProgress, u64) -> bool`; `true` cancels and the pass already rendered is
+ * dropped; the last image is delivered after the loop and its return value is ignored (:82-98).
+ * rt_sample_image keeps that shape with `batch` passes per image (0 = all of them in one batch): batch j+1
+ * renders on the GPU while batch j is copied to pinned host memory on a second HIP stream and the
+ * callback runs, from two device and two pinned host buffers owned by the scene.  `progress->current_image`
+ * is the MEAN of the batch's passes (samples_completed of them; layout per opts->output_layout), valid
+ * during the callback only; `samples_done` counts passes delivered so far including this batch.  With
+ * batch = 1 the contract is the reference's, image for image.  Blocking; one host thread per scene. ---- */
+typedef struct rt_sampler_progress { /* SamplerProgress  samplers/mod.rs:49-53 */
+	uint64_t samples_completed;
+	uint64_t rays_shot;
+	const float *current_image;
+	uint64_t n_floats;
+} rt_sampler_progress;
+typedef int (*rt_presentation_update)(void *data, const rt_sampler_progress *progress, uint64_t samples_done);
+int rt_sample_image(rt_scene *scene, const rt_camera *camera, const rt_render_opts *opts, uint64_t batch,
+                    rt_presentation_update update, void *data);
+
 /* Milliseconds the GPU spent in the render kernel of the most recent rt_render /
  * rt_render_device on this scene, measured with HIP events on the launch stream
  * (synchronises that stream).  The kernel's launch count is returned through n_launches. */

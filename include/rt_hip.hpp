@@ -52,6 +52,18 @@ struct SamplerProgress { // samplers/mod.rs:49-63
 	std::vector<float> current_image;
 	SamplerProgress(uint64_t pixel_num, uint64_t channels) : current_image(pixel_num * channels, 0.0f) {}
 };
+// `&SamplerProgress` as the presentation callback sees it: the image lives in the sampler's pinned buffer
+struct SamplerProgressRef {
+	uint64_t samples_completed = 0;
+	uint64_t rays_shot = 0;
+	struct Image {
+		const float *ptr = nullptr;
+		size_t n = 0;
+		const float *data() const { return ptr; }
+		size_t size() const { return n; }
+		float operator[](size_t k) const { return ptr[k]; }
+	} current_image;
+};
 
 class SimpleCamera { // camera.rs:6-54
   public:
@@ -207,29 +219,35 @@ struct HipSampler {
 	uint64_t seed = 1;
 	uint32_t max_depth = 50, rr_threshold = 3; // integrators/mod.rs:7-8
 
+	// update(data, previous, i) -> bool, the reference's presentation_update: called once per batch with the
+	// batch's mean image while the next batch renders; `true` cancels (random_sampler.rs:82-98)
 	template <class T, class F>
 	void sample_image(const RenderOptions &o, const SimpleCamera &camera, const Bvh &bvh, T *data, F update) const
 	{
-		SamplerProgress progress(o.width * o.height, 3);
 		rt_render_opts opts;
 		rt_render_opts_default(&opts);
 		opts.width = o.width;
 		opts.height = o.height;
+		opts.samples_per_pixel = o.samples_per_pixel;
 		opts.seed = seed;
 		opts.render_method = (int32_t)o.render_method;
 		opts.max_depth = max_depth;
 		opts.rr_threshold = rr_threshold;
-		uint64_t done = 0;
-		while (done < o.samples_per_pixel) {
-			const uint64_t n = batch == 0 ? o.samples_per_pixel - done : std::min(batch, o.samples_per_pixel - done);
-			opts.samples_per_pixel = n;
-			opts.sample_begin = done;
-			check(rt_render(bvh.raw(), &camera.raw(), &opts, progress.current_image.data(), &progress.rays_shot));
-			done += n;
-			progress.samples_completed = n;
-			if (update(data, progress, done) && done < o.samples_per_pixel)
-				return;
-		}
+		struct Closure {
+			T *data;
+			F *update;
+		} closure{data, &update};
+		check(rt_sample_image(bvh.raw(), &camera.raw(), &opts, batch,
+		                      [](void *c, const rt_sampler_progress *p, uint64_t done) -> int {
+			                      auto *cl = static_cast<Closure *>(c);
+			                      SamplerProgressRef ref;
+			                      ref.samples_completed = p->samples_completed;
+			                      ref.rays_shot = p->rays_shot;
+			                      ref.current_image.ptr = p->current_image;
+			                      ref.current_image.n = (size_t)p->n_floats;
+			                      return (*cl->update)(cl->data, ref, done) ? 1 : 0;
+		                      },
+		                      &closure));
 	}
 };
 
@@ -237,7 +255,7 @@ struct Presentation { // what render_tui keeps: the mean image and the ray total
 	SamplerProgress sampler_progress;
 	Presentation(uint64_t pixel_num) : sampler_progress(pixel_num, 3) {}
 };
-inline bool running_mean(Presentation *sp, const SamplerProgress &previous, uint64_t i)
+inline bool running_mean(Presentation *sp, const SamplerProgressRef &previous, uint64_t i)
 {
 	sp->sampler_progress.samples_completed += previous.samples_completed;
 	sp->sampler_progress.rays_shot += previous.rays_shot;

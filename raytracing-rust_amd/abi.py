@@ -169,6 +169,18 @@ class BvhNode(C.Structure):
 
 
 # sizes the C compiler must agree with (x86-64 SysV); checked by tests/test_abi.py
+class SamplerProgressC(C.Structure):  # rt_sampler_progress
+    _fields_ = [
+        ("samples_completed", C.c_uint64),
+        ("rays_shot", C.c_uint64),
+        ("current_image", C.POINTER(C.c_float)),
+        ("n_floats", C.c_uint64),
+    ]
+
+
+# rt_presentation_update: int (*)(void *data, const rt_sampler_progress *, uint64_t samples_done)
+PresentationUpdate = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SamplerProgressC), C.c_uint64)
+
 EXPECTED_SIZES = {
     "rt_texture_desc": (TextureDesc, 64),
     "rt_material_desc": (MaterialDesc, 28),
@@ -182,6 +194,7 @@ EXPECTED_SIZES = {
     "rt_hit_record": (HitRecord, 72),
     "rt_ray_desc": (RayDesc, 24),
     "rt_bvh_node": (BvhNode, 56),
+    "rt_sampler_progress": (SamplerProgressC, 32),
 }
 
 # every symbol include/rt_hip.h declares
@@ -200,6 +213,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",
     "rt_render",
+    "rt_sample_image",
     "rt_render_device",
     "rt_render_output_floats",
     "rt_shard_pixel_order",

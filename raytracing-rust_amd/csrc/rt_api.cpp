@@ -81,6 +81,14 @@ struct rt_scene {
 	bool scene_lds_allowed = true;
 	float *d_partial = nullptr; // sample_split > 1: per-chunk means, grown on demand
 	size_t partial_floats = 0;
+	// rt_sample_image: two batches in flight (device + pinned host buffers, copy stream, events)
+	float *d_prog[2] = {nullptr, nullptr};
+	float *h_prog[2] = {nullptr, nullptr};
+	unsigned long long *d_prog_rays = nullptr; // [2]
+	unsigned long long *h_prog_rays = nullptr; // [2], pinned
+	size_t prog_floats = 0;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	size_t max_lds = 65536;
 };
 
@@ -143,6 +151,15 @@ void rt_scene_destroy(rt_scene *s)
 		(void)hipFree(p);
 	if (s->d_partial)
 		(void)hipFree(s->d_partial);
+	for (int b = 0; b < 2; ++b) {
+		if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
+		if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
+		if (s->ev_batch[b]) (void)hipEventDestroy(s->ev_batch[b]);
+		if (s->ev_copy[b]) (void)hipEventDestroy(s->ev_copy[b]);
+	}
+	if (s->d_prog_rays) (void)hipFree(s->d_prog_rays);
+	if (s->h_prog_rays) (void)hipHostFree(s->h_prog_rays);
+	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 	if (s->ev_start)
 		(void)hipEventDestroy(s->ev_start);
 	if (s->ev_stop)
@@ -591,6 +608,100 @@ int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, flo
 	}
 	(void)hipFree(d_out);
 	return rc;
+}
+
+int rt_sample_image(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, uint64_t batch, rt_presentation_update update, void *data)
+{
+	if (!s || !camera || !o)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	uint64_t n_floats = 0;
+	int rc = rt_render_output_floats(o, &n_floats);
+	if (rc != RT_OK)
+		return rc;
+	const uint64_t spp = o->samples_per_pixel;
+	if (spp == 0 || spp >= (1ull << 32))
+		return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be in [1, 2^32)");
+	if (batch == 0 || batch > spp)
+		batch = spp;
+	HIP_TRY(hipSetDevice(s->device));
+	if (!s->copy_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+		for (int b = 0; b < 2; ++b) {
+			HIP_TRY(hipEventCreateWithFlags(&s->ev_batch[b], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&s->ev_copy[b], hipEventDisableTiming));
+		}
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog_rays), 2 * sizeof(unsigned long long)));
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog_rays), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	if (n_floats > s->prog_floats) { // grows on first use / larger frames only
+		for (int b = 0; b < 2; ++b) {
+			if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
+			if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
+			s->d_prog[b] = nullptr;
+			s->h_prog[b] = nullptr;
+		}
+		s->prog_floats = 0;
+		for (int b = 0; b < 2; ++b) {
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog[b]), n_floats * sizeof(float)));
+			HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog[b]), n_floats * sizeof(float), hipHostMallocDefault));
+		}
+		s->prog_floats = n_floats;
+	}
+
+	const uint64_t n_batches = (spp + batch - 1) / batch;
+	uint64_t delivered = 0;
+	// deliver batch j (its copy was enqueued on copy_stream): wait for the copy, run the callback
+	auto deliver = [&](uint64_t j, bool &cancel) -> int {
+		const int b = (int)(j & 1);
+		HIP_TRY(hipEventSynchronize(s->ev_copy[b]));
+		const uint64_t nb = std::min<uint64_t>(batch, spp - j * batch);
+		delivered += nb;
+		cancel = false;
+		if (update) {
+			rt_sampler_progress p;
+			p.samples_completed = nb;
+			p.rays_shot = s->h_prog_rays[b];
+			p.current_image = s->h_prog[b];
+			p.n_floats = n_floats;
+			cancel = update(data, &p, delivered) != 0;
+		}
+		return RT_OK;
+	};
+	for (uint64_t j = 0; j < n_batches; ++j) {
+		const int b = (int)(j & 1);
+		rt_render_opts oj = *o;
+		oj.samples_per_pixel = std::min<uint64_t>(batch, spp - j * batch);
+		oj.sample_begin = o->sample_begin + j * batch;
+		if (oj.sample_split > oj.samples_per_pixel)
+			oj.sample_split = (uint32_t)oj.samples_per_pixel;
+		rc = rt_render_device(s, camera, &oj, s->d_prog[b], reinterpret_cast<uint64_t *>(s->d_prog_rays + b), s->stream);
+		if (rc != RT_OK)
+			break;
+		HIP_TRY(hipEventRecord(s->ev_batch[b], s->stream));
+		HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_batch[b], 0));
+		if (n_floats)
+			HIP_TRY(hipMemcpyAsync(s->h_prog[b], s->d_prog[b], n_floats * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+		HIP_TRY(hipMemcpyAsync(s->h_prog_rays + b, s->d_prog_rays + b, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->copy_stream));
+		HIP_TRY(hipEventRecord(s->ev_copy[b], s->copy_stream));
+		if (j > 0) { // the previous batch goes to the callback while this one renders (random_sampler.rs:82-90)
+			bool cancel = false;
+			rc = deliver(j - 1, cancel);
+			if (rc != RT_OK)
+				break;
+			if (cancel) { // `return` inside the loop: the batch in flight is dropped
+				HIP_TRY(hipStreamSynchronize(s->stream));
+				HIP_TRY(hipStreamSynchronize(s->copy_stream));
+				return RT_OK;
+			}
+		}
+	}
+	if (rc != RT_OK) {
+		(void)hipStreamSynchronize(s->stream);
+		(void)hipStreamSynchronize(s->copy_stream);
+		return rc;
+	}
+	bool ignored = false; // random_sampler.rs:92-98: the last image, return value ignored
+	return deliver(n_batches - 1, ignored);
 }
 
 int rt_last_kernel_ms(rt_scene *s, float *ms, uint32_t *n_launches)

@@ -10,6 +10,7 @@ every call raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -33,6 +34,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RtHipError(abi.RT_ERR_NO_DEVICE, f"{LIB_PATH} not built (run `make -C raytracing-rust_amd/csrc`); "
                              "the HIP back end has no CPU fallback")
+        # PyTorch-ROCm ships its own HIP/HSA runtime.  A process that uses both (bench.py, the RCCL gather,
+        # the HIP-graph test) must have torch's copy loaded BEFORE librt_hip.so pulls in /opt/rocm's: in the
+        # reverse order torch later finds "No HIP GPUs".  So if torch is installed, import it first.
+        if "torch" not in sys.modules and os.environ.get("RT_HIP_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _LIB = C.CDLL(LIB_PATH)
         _LIB.rt_last_error.restype = C.c_char_p
         _LIB.rt_abi_version.restype = C.c_uint32
@@ -210,24 +219,29 @@ class RandomSampler:
         self.batch = batch
 
     def sample_image(self, render_options, camera, scene, presentation_update=None):
+        """rt_sample_image: batch j+1 renders while batch j is copied out and handed to the callback."""
         opts = _with_layout(render_options, abi.RT_LAYOUT_FRAME)
-        spp = int(render_options.samples_per_pixel)
-        batch = self.batch or spp
-        progress = SamplerProgress(int(opts.width * opts.height))
-        done = 0
-        while done < spp:
-            nb = min(batch, spp - done)
-            opts.samples_per_pixel = nb
-            opts.sample_begin = int(render_options.sample_begin) + done
-            img, rays = scene.render(camera, opts)
-            done += nb
-            progress.current_image = img.reshape(-1)
-            progress.rays_shot = rays
-            progress.samples_completed = nb
-            if presentation_update is not None:
+        state = {"error": None}
+
+        def trampoline(_data, p, done):
+            try:
+                progress = SamplerProgress(0)
+                progress.samples_completed = int(p.contents.samples_completed)
+                progress.rays_shot = int(p.contents.rays_shot)
+                # a view of the sampler's pinned buffer: valid during the callback only
+                progress.current_image = np.ctypeslib.as_array(p.contents.current_image, shape=(int(p.contents.n_floats),))
+                if presentation_update is None:
+                    return 0
                 data, f = presentation_update
-                if f(data, progress, done) and done < spp:
-                    return
+                return 1 if f(data, progress, int(done)) else 0
+            except BaseException as e:  # an exception must not unwind through the C frames
+                state["error"] = e
+                return 1
+
+        cb = abi.PresentationUpdate(trampoline)
+        _check(lib().rt_sample_image(scene._h, C.byref(camera), C.byref(opts), C.c_uint64(self.batch or 0), cb, None))
+        if state["error"] is not None:
+            raise state["error"]
 
 
 def running_mean_update(image, progress, i):

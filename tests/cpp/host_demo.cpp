@@ -36,7 +36,7 @@ int main(int argc, char **argv)
 
 		Presentation image(o.width * o.height);
 		int calls = 0;
-		sampler.sample_image(o, camera, bvh, &image, [&](Presentation *p, const SamplerProgress &prev, uint64_t i) {
+		sampler.sample_image(o, camera, bvh, &image, [&](Presentation *p, const SamplerProgressRef &prev, uint64_t i) {
 			++calls;
 			return running_mean(p, prev, i);
 		});
