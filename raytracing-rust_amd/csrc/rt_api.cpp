@@ -86,7 +86,7 @@ struct rt_scene {
 	float *h_prog[2] = {nullptr, nullptr};
 	unsigned long long *d_prog_rays = nullptr; // [2]
 	unsigned long long *h_prog_rays = nullptr; // [2], pinned
-	size_t prog_floats = 0;
+	size_t d_prog_floats[2] = {0, 0}, h_prog_floats[2] = {0, 0};
 	hipStream_t copy_stream = nullptr;
 	hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	size_t max_lds = 65536;
@@ -411,6 +411,43 @@ int shard_geometry(const rt_render_opts *o, ShardGeometry &g)
 
 } // namespace
 
+// Scene-owned frame buffers, grown on first use / larger frames only: rt_render needs one device frame,
+// rt_sample_image two device frames, two pinned host frames, a copy stream and its events.
+static int ensure_frame_buffers(rt_scene *s, uint64_t n_floats, bool progressive)
+{
+	const int n_dev = progressive ? 2 : 1;
+	for (int b = 0; b < n_dev; ++b) {
+		if (n_floats <= s->d_prog_floats[b])
+			continue;
+		if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
+		s->d_prog[b] = nullptr;
+		s->d_prog_floats[b] = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog[b]), n_floats * sizeof(float)));
+		s->d_prog_floats[b] = n_floats;
+	}
+	if (!progressive)
+		return RT_OK;
+	if (!s->copy_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+		for (int b = 0; b < 2; ++b) {
+			HIP_TRY(hipEventCreateWithFlags(&s->ev_batch[b], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&s->ev_copy[b], hipEventDisableTiming));
+		}
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog_rays), 2 * sizeof(unsigned long long)));
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog_rays), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	for (int b = 0; b < 2; ++b) {
+		if (n_floats <= s->h_prog_floats[b])
+			continue;
+		if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
+		s->h_prog[b] = nullptr;
+		s->h_prog_floats[b] = 0;
+		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog[b]), n_floats * sizeof(float), hipHostMallocDefault));
+		s->h_prog_floats[b] = n_floats;
+	}
+	return RT_OK;
+}
+
 extern "C" {
 
 int rt_render_output_floats(const rt_render_opts *o, uint64_t *n_floats)
@@ -594,8 +631,10 @@ int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, flo
 	if (!out_rgb)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	HIP_TRY(hipSetDevice(s->device));
-	float *d_out = nullptr;
-	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), n_floats * sizeof(float)));
+	rc = ensure_frame_buffers(s, n_floats, false); // scene-owned device frame: no allocation per call
+	if (rc != RT_OK)
+		return rc;
+	float *d_out = s->d_prog[0];
 	rc = rt_render_device(s, camera, o, d_out, reinterpret_cast<uint64_t *>(s->d_rays), s->stream);
 	if (rc == RT_OK) {
 		hipError_t e = hipMemcpyAsync(out_rgb, d_out, n_floats * sizeof(float), hipMemcpyDeviceToHost, s->stream);
@@ -606,7 +645,6 @@ int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, flo
 		if (e != hipSuccess)
 			rc = hip_fail(e, "render");
 	}
-	(void)hipFree(d_out);
 	return rc;
 }
 
@@ -624,29 +662,9 @@ int rt_sample_image(rt_scene *s, const rt_camera *camera, const rt_render_opts *
 	if (batch == 0 || batch > spp)
 		batch = spp;
 	HIP_TRY(hipSetDevice(s->device));
-	if (!s->copy_stream) {
-		HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-		for (int b = 0; b < 2; ++b) {
-			HIP_TRY(hipEventCreateWithFlags(&s->ev_batch[b], hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&s->ev_copy[b], hipEventDisableTiming));
-		}
-		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog_rays), 2 * sizeof(unsigned long long)));
-		HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog_rays), 2 * sizeof(unsigned long long), hipHostMallocDefault));
-	}
-	if (n_floats > s->prog_floats) { // grows on first use / larger frames only
-		for (int b = 0; b < 2; ++b) {
-			if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
-			if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
-			s->d_prog[b] = nullptr;
-			s->h_prog[b] = nullptr;
-		}
-		s->prog_floats = 0;
-		for (int b = 0; b < 2; ++b) {
-			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_prog[b]), n_floats * sizeof(float)));
-			HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_prog[b]), n_floats * sizeof(float), hipHostMallocDefault));
-		}
-		s->prog_floats = n_floats;
-	}
+	rc = ensure_frame_buffers(s, n_floats, true);
+	if (rc != RT_OK)
+		return rc;
 
 	const uint64_t n_batches = (spp + batch - 1) / batch;
 	uint64_t delivered = 0;
