@@ -381,14 +381,26 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uin
 	return stk[sp * kStackStride];
 }
 
+// The root test of Bvh::get_intersection_candidates (mod.rs:203-210).  It decides something only when the
+// root is a leaf: an inner root's bounds contain both children's, and the slab test is monotone in the
+// bounds (each t interval of the larger box contains the smaller box's; a NaN from 0 * inf is ignored by
+// min/max on either side), so "root missed" implies "both children missed" and the walk below finds
+// nothing anyway.  The branch is wave-uniform.
+__device__ __forceinline__ bool root_box_misses(const DevScene &S, const Ray &r)
+{
+	if (!ref_is_leaf(S.root_ref))
+		return false;
+	float tm;
+	return !aabb_does_int(S.root_min, S.root_max, r, tm);
+}
+
 // Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
 template <class F, bool PRUNE>
 __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
 {
 	best_t = 0.0f;
 	best_prim = kNoPrim;
-	float tm;
-	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
+	if (root_box_misses(S, r))
 		return;
 	int sp = 0;
 	uint32_t node = S.root_ref;
@@ -432,8 +444,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 template <class F, bool PRUNE>
 __device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
 {
-	float tm;
-	if (!aabb_does_int(S.root_min, S.root_max, r, tm))
+	if (root_box_misses(S, r))
 		return false;
 	const bool limited = !(t_limit != t_limit);
 	int sp = 0;

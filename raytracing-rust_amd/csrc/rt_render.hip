@@ -217,8 +217,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 			ph = PH_NODE;
 			return;
 		}
-		float tm;
-		if (aabb_does_int(S.root_min, S.root_max, ray, tm)) {
+		if (!root_box_misses(S, ray)) {
 			node = S.root_ref;
 			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
 		} else {
