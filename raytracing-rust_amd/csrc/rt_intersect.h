@@ -394,14 +394,73 @@ __device__ __forceinline__ bool root_box_misses(const DevScene &S, const Ray &r)
 	return !aabb_does_int(S.root_min, S.root_max, r, tm);
 }
 
+// the primitive loop of Bvh::check_hit for one leaf: selection rule of mod.rs:270-293
+template <class F>
+__device__ __forceinline__ void closest_in_leaf(const DevScene &S, const Ray &r, uint32_t leaf, float &best_t, uint32_t &best_prim)
+{
+	uint32_t first, count;
+	leaf_range(S, leaf, first, count);
+	for (uint32_t slot = first; slot < first + count; ++slot) {
+		const PrimGeom g = load_prim<F>(S, slot);
+		float t;
+		if (prim_t<F>(g, r, t) && t > 0.0f) {
+			bool take;
+			if (best_prim == kNoPrim)
+				take = true;
+			else if (t < best_t)
+				take = true;
+			else if (t == best_t)
+				take = S.prim_rank[slot] < S.prim_rank[best_prim]; // reference order: first in BFS-leaf order wins
+			else
+				take = false;
+			if (take) {
+				best_t = t;
+				best_prim = slot;
+			}
+		}
+	}
+}
+// ... and of the occlusion rule (see trace_any)
+template <class F>
+__device__ __forceinline__ bool any_in_leaf(const DevScene &S, const Ray &r, uint32_t leaf, float t_limit, uint32_t skip)
+{
+	uint32_t first, count;
+	leaf_range(S, leaf, first, count);
+	for (uint32_t slot = first; slot < first + count; ++slot) {
+		if (slot == skip)
+			continue;
+		const PrimGeom g = load_prim<F>(S, slot);
+		float t;
+		if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
+			return true;
+	}
+	return false;
+}
+// A tree of one inner node over two leaves (rtweekend1: ground sphere + ball) needs no loop and no stack:
+// both child boxes, then the leaves whose box was hit, in the reference's candidate order.  Wave-uniform.
+__device__ __forceinline__ bool is_two_leaf_tree(const DevScene &S) { return S.n_nodes == 1u && !ref_is_leaf(S.root_ref); }
+
 // Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
 template <class F, bool PRUNE>
-__device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
+__device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene &SU, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
 {
 	best_t = 0.0f;
 	best_prim = kNoPrim;
 	if (root_box_misses(S, r))
 		return;
+	if (!PRUNE && is_two_leaf_tree(S)) {
+		// SU is the scene as the kernel received it (global memory): every address below is wave-uniform,
+		// so the node and the primitives arrive through scalar loads and the tests read them from SGPRs
+		const NodeView n = load_node(SU, 0u);
+		float t0, t1;
+		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+#pragma unroll 1
+		for (int c = 0; c < 2; ++c)
+			if (c == 0 ? h0 : h1)
+				closest_in_leaf<F>(SU, r, c == 0 ? n.c0 : n.c1, best_t, best_prim);
+		return;
+	}
 	int sp = 0;
 	uint32_t node = S.root_ref;
 	while (node != kRefDone) {
@@ -409,27 +468,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 			node = descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
-		uint32_t first, count;
-		leaf_range(S, node, first, count);
-		for (uint32_t slot = first; slot < first + count; ++slot) { // selection rule of mod.rs:270-293
-			const PrimGeom g = load_prim<F>(S, slot);
-			float t;
-			if (prim_t<F>(g, r, t) && t > 0.0f) {
-				bool take;
-				if (best_prim == kNoPrim)
-					take = true;
-				else if (t < best_t)
-					take = true;
-				else if (t == best_t)
-					take = S.prim_rank[slot] < S.prim_rank[best_prim]; // reference order: first in BFS-leaf order wins
-				else
-					take = false;
-				if (take) {
-					best_t = t;
-					best_prim = slot;
-				}
-			}
-		}
+		closest_in_leaf<F>(S, r, node, best_t, best_prim);
 		if (sp == 0)
 			break;
 		--sp;
@@ -442,11 +481,23 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const Ray &r, u
 // some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
 // limit" (any t > 0 occludes).
 template <class F, bool PRUNE>
-__device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
+__device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
 {
 	if (root_box_misses(S, r))
 		return false;
 	const bool limited = !(t_limit != t_limit);
+	if (!PRUNE && is_two_leaf_tree(S)) {
+		const NodeView n = load_node(SU, 0u);
+		float t0, t1;
+		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		bool occluded = false;
+#pragma unroll 1
+		for (int c = 0; c < 2; ++c)
+			if (!occluded && (c == 0 ? h0 : h1))
+				occluded = any_in_leaf<F>(SU, r, c == 0 ? n.c0 : n.c1, t_limit, skip);
+		return occluded;
+	}
 	int sp = 0;
 	uint32_t node = S.root_ref;
 	while (node != kRefDone) {
@@ -454,16 +505,8 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const Ray &r, uint3
 			node = descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
-		uint32_t first, count;
-		leaf_range(S, node, first, count);
-		for (uint32_t slot = first; slot < first + count; ++slot) {
-			if (slot == skip)
-				continue;
-			const PrimGeom g = load_prim<F>(S, slot);
-			float t;
-			if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
-				return true;
-		}
+		if (any_in_leaf<F>(S, r, node, t_limit, skip))
+			return true;
 		if (sp == 0)
 			break;
 		--sp;

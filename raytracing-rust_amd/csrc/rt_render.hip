@@ -552,13 +552,13 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	// of rt_intersect.h (closest walk in the TRACE super-phase, shadow walk in the LIGHT super-phase)
 	auto walk_closest_pending = [&]() {
 		if (ph == PH_NODE && !any_hit) {
-			trace_closest<F, PRUNE>(S, ray, stk, best_t, best_prim);
+			trace_closest<F, PRUNE>(S, S_global, ray, stk, best_t, best_prim);
 			ph = PH_SHADE;
 		}
 	};
 	auto walk_shadow_pending = [&](const LightCtx &L, const Ray &sr) {
 		if (ph == PH_NODE && any_hit) {
-			best_prim = trace_any<F, PRUNE>(S, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
+			best_prim = trace_any<F, PRUNE>(S, S_global, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
 			ph = PH_SCATTER;
 		}
 	};
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void check_hit_kernel(const DevScene S, const 
 	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
 	float t;
 	uint32_t prim;
-	trace_closest<F, PRUNE>(S, r, stk, t, prim);
+	trace_closest<F, PRUNE>(S, S, r, stk, t, prim);
 	Hit h;
 	uint32_t m;
 	if (prim != kNoPrim) {
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 	bool found = false;
 	float lt;
 	if (prim_t<F>(g, r, lt) && lt > 0.0f) {
-		if (!trace_any<F, PRUNE>(S, r, stk, lt, index)) {
+		if (!trace_any<F, PRUNE>(S, S, r, stk, lt, index)) {
 			make_hit<F>(S, index, r, lt, h, m);
 			found = true;
 		}
