@@ -27,13 +27,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, SPP = 1920, 1080, 1024
-SCENE = "rtweekend1"
-SEED = 1
+WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# SURVEY 8(d) algorithmic bytes per sample for this workload, counted by tests/count_algorithmic_bytes.py
-# (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest hit, 64 B/sky op, 12 B/pixel)
-ALGORITHMIC_BYTES_PER_SAMPLE = 446.77
+# The default workload is BASELINE.json configs[1]; --workload selects configs[2] / configs[3] for the numbers
+# quoted in DESIGN.md.  bytes = SURVEY 8(d) algorithmic bytes per sample, counted by
+# tests/count_algorithmic_bytes.py (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest hit,
+# 64 B/sky op, 12 B/pixel) -> profiles/algorithmic_bytes.json
+WORKLOADS = {
+    "rtweekend1": {"spp": 1024, "seed": 1, "bytes": 446.77, "feat": "rt::Feat<false, false, false, false>", "variant": "1, false, false, true"},
+    "overshadowed": {"spp": 1024, "seed": 1, "bytes": 488.42, "feat": "rt::Feat<true, true, false, false>", "variant": "1, false, false, true"},
+    "mesh1m": {"spp": 256, "seed": 42, "bytes": 38990.98, "feat": "rt::Feat<true, true, false, false>", "variant": "1, true, true, false"},
+}
+SCENE, SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE = "rtweekend1", 1024, 1, 446.77
+
+
+def load_workload(pkg, name):
+    """(scene description, camera parameters) of a workload"""
+    if name == "mesh1m":  # BASELINE configs[3]: the synthetic 1 M random-triangle mesh (generator: tests/scenes.py)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes
+        return scenes.random_triangle_mesh(1000000, seed=42), dict(scenes.MESH_CAMERA)
+    ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", name + ".ssml"))
+    return ls.scene, ls.camera_params
 
 
 def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=12.0):
@@ -44,15 +59,18 @@ def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=12.0):
     cores = os.cpu_count() or 1
     s = O.Scene(scene_desc)
     cam = O.camera_new(**camera_params)
+    # calibration, untimed: a strip of the frame at 2 spp (the big mesh needs seconds per full pass on the CPU)
+    strip = abi.default_render_opts(WIDTH, HEIGHT, 2, seed=SEED)
+    strip.shard_index, strip.shard_count = 0, 16  # every 16th tile, interleaved over the whole frame
     t0 = time.time()
-    s.render(cam, abi.default_render_opts(WIDTH, HEIGHT, 8, seed=SEED), n_threads=cores)  # calibration, untimed
-    per_spp = max((time.time() - t0) / 8.0, 1e-3)
-    spp = int(max(2, min(512, target_seconds / per_spp)))
+    s.render(cam, strip, n_threads=cores)
+    per_spp = max((time.time() - t0) * 16.0 / 2.0, 1e-3)
+    spp = int(max(1, min(512, SPP, target_seconds / per_spp)))
     t0 = time.time()
     s.render(cam, abi.default_render_opts(WIDTH, HEIGHT, spp, seed=SEED), n_threads=cores)
     dt = time.time() - t0
     return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{SCENE}.ssml {WIDTH}x{HEIGHT}, {spp} of {SPP} spp, MIS, max_depth 50, {dt:.1f} s of CPU work"}
+            "sample": f"{SCENE} {WIDTH}x{HEIGHT}, {spp} of {SPP} spp, MIS, max_depth 50, {dt:.1f} s of CPU work"}
 
 
 def main():
@@ -61,7 +79,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="rtweekend1")
     args = ap.parse_args()
+    global SCENE, SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE
+    SCENE = args.workload
+    SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE = WORKLOADS[SCENE]["spp"], WORKLOADS[SCENE]["seed"], WORKLOADS[SCENE]["bytes"]
 
     import torch
     import torch.distributed as dist
@@ -86,11 +108,11 @@ def main():
     D = importlib.import_module("raytracing-rust_amd.distributed")
     abi = pkg.abi
 
-    ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", SCENE + ".ssml"))
+    scene_desc, camera_params = load_workload(pkg, SCENE)
     t0 = time.time()
-    scene = hb.HipScene(ls.scene, device=local_rank)  # BVH build + upload: not part of the timed region
+    scene = hb.HipScene(scene_desc, device=local_rank)  # BVH build + upload: not part of the timed region
     build_s = time.time() - t0
-    cam = hb.camera_new(**ls.camera_params)
+    cam = hb.camera_new(**camera_params)
 
     opts = abi.default_render_opts(WIDTH, HEIGHT, SPP, method=abi.RT_METHOD_MIS, seed=SEED)
     # A lane folds a whole pixel by default (the reference's sequential running mean), so a GPU cannot
@@ -150,7 +172,7 @@ def main():
         if os.path.exists(tp) and world == 1:
             traffic = json.load(open(tp)).get(f"{SCENE}_{WIDTH}x{HEIGHT}x{SPP}_mis", {}).get("hbm_bytes_per_launch")
         out = {
-            "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp",
+            "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp" if SCENE == "rtweekend1" else f"Msamples/s on {SCENE} {WIDTH}x{HEIGHT}x{SPP}spp",
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -162,21 +184,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"scenes/{SCENE}.ssml {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={SEED}",
+            "config": {"workload": (f"scenes/{SCENE}.ssml" if SCENE != "mesh1m" else "synthetic 1M random-triangle mesh (BASELINE configs[3])") +
+                                   f" {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={SEED}",
                        "parallelism": f"tile-sharded x{world}, replicated BVH, one RCCL gather per frame" if world > 1 else "1 GPU",
                        "sample_split": split,
                        "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
                        "scene_build_s": build_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rt::render_kernel<1, false, false, true, rt::Feat<false, false, false, false>>", "kernel_ms": k_ms,
+                         "kernel": f"rt::render_kernel<{WORKLOADS[SCENE]['variant']}, {WORKLOADS[SCENE]['feat']}>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE,
-                         "note": "algorithmic (requested) bytes under reference traversal semantics; the 2-sphere scene and "
-                                 "its 41 KB sky table live in LDS/L1/L2, so real HBM traffic is ~12 B/pixel (see traffic) and "
-                                 "this kernel is VALU/latency-bound, not HBM-bound, by design"},
+                         "note": ("algorithmic (requested) bytes under reference traversal semantics; the scene and "
+                                  "its 41 KB sky table live in LDS/L1/L2, so real HBM traffic is ~12 B/pixel (see traffic) and "
+                                  "this kernel is VALU/latency-bound, not HBM-bound, by design") if SCENE != "mesh1m" else
+                                 ("algorithmic (requested) bytes under reference traversal semantics (no pruning); the pruned walk "
+                                  "requests 2.8x fewer and is bound by the random 64-byte fetch rate of L2/Infinity Cache "
+                                  "(DESIGN.md section 5)")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, ls.scene, ls.camera_params)
+            out["cpu_baseline"] = cpu_baseline(pkg, scene_desc, camera_params)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
