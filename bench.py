@@ -36,7 +36,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     "rtweekend1": {"spp": 1024, "seed": 1, "bytes": 446.77, "feat": "rt::Feat<false, false, false, false>", "variant": "1, false, false, true"},
     "overshadowed": {"spp": 1024, "seed": 1, "bytes": 488.42, "feat": "rt::Feat<true, true, false, false>", "variant": "1, false, false, true"},
-    "mesh1m": {"spp": 256, "seed": 42, "bytes": 38990.98, "feat": "rt::Feat<true, true, false, false>", "variant": "1, true, true, false"},
+    # walk_bytes: what the pruned GPU walk itself requests per sample, from the -DRT_STATS diagnostic build
+    # (tests/gpu_stats_fine.py: 330.0 node steps x 64 B + 5.95 primitive tests x 48 B + 0.67 hits x 48 B normals)
+    "mesh1m": {"spp": 256, "seed": 42, "bytes": 38990.98, "feat": "rt::Feat<true, true, false, false>", "variant": "1, true, true, false",
+               "walk_bytes": 330.0 * 64 + 5.95 * 48 + 0.67 * 48},
 }
 SCENE, SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE = "rtweekend1", 1024, 1, 446.77
 
@@ -201,6 +204,10 @@ def main():
                                   "requests 2.8x fewer and is bound by the random 64-byte fetch rate of L2/Infinity Cache "
                                   "(DESIGN.md section 5)")},
         }
+        if "walk_bytes" in WORKLOADS[SCENE]:
+            wb = WORKLOADS[SCENE]["walk_bytes"]
+            out["roofline"]["pruned_walk_bytes_per_sample"] = wb
+            out["roofline"]["pruned_walk_requested_GBps"] = wb * launch_samples / (k_ms * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, scene_desc, camera_params)
         print(json.dumps(out), flush=True)
