@@ -52,8 +52,9 @@ enum : int {
 };
 
 // coarse schedule: the LIGHT super-phase runs once this many lanes of the wave wait for it
+// (rtweekend1 MIS, same box: 32 -> 152 ms, 40 -> 138 ms, 48 / 52 / 56 -> 135-137 ms)
 #ifndef RT_LIGHT_PHASE_THRESHOLD
-#define RT_LIGHT_PHASE_THRESHOLD 40
+#define RT_LIGHT_PHASE_THRESHOLD 48
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
