@@ -53,6 +53,9 @@ enum : int {
 
 // coarse schedule: the LIGHT super-phase runs once this many lanes of the wave wait for it
 // (rtweekend1 MIS, same box: 32 -> 152 ms, 40 -> 138 ms, 48 / 52 / 56 -> 135-137 ms)
+#ifndef RT_PQ_SPLIT
+#define RT_PQ_SPLIT 1
+#endif
 #ifndef RT_LIGHT_PHASE_THRESHOLD
 #define RT_LIGHT_PHASE_THRESHOLD 48
 #endif
@@ -341,7 +344,10 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 	};
 
 	// SHADE -- the walk of a path ray ended: integrators/mod.rs:31-72 (naive), mis.rs:17-33,50-86 (MIS)
-	auto do_shade = [&]() {
+	// `arm`: 0 = either arm of the MIS shade (fine schedule), 1 = only primary lanes can be here, 2 = only
+	// bounce lanes can be here (coarse schedule, see the super-phases below): the other arm is not compiled in
+	auto do_shade = [&](auto arm_tag) {
+		constexpr int arm = decltype(arm_tag)::value;
 		const uint32_t prim = best_prim;
 		bool finish = false;
 		bool filter = true;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 						finish = true;
 				}
 			}
-		} else if (primary) {
+		} else if (arm == 1 || (arm == 0 && primary)) {
 			// ---- MisIntegrator::get_colour prologue  mis.rs:17-33 ----
 			wo = ray.d;
 			hit = nh;
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 					do_gen();
 			} else if (run == PH_SHADE) {
 				if (ph == PH_SHADE)
-					do_shade();
+					do_shade(std::integral_constant<int, 0>{});
 			} else if (run == PH_LIGHT) {
 				if (ph == PH_LIGHT)
 					do_light(PL, ray);
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 					do_gen();
 				walk_closest_pending();
 				if (ph == PH_SHADE)
-					do_shade();
+					do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
 			} else {
 				LightCtx L; // loop-local: see LightCtx above
 				L.l_wi = v3s(0.0f);
@@ -727,6 +733,13 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 				walk_shadow_pending(L, sray);
 				if (ph == PH_SCATTER)
 					do_scatter(L, sray);
+#if RT_PQ_SPLIT
+				// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
+				// the other super-phase only ever holds primary lanes and neither arm runs half empty
+				walk_closest_pending();
+				if (ph == PH_SHADE)
+					do_shade(std::integral_constant<int, 2>{});
+#endif
 			}
 		}
 	}
