@@ -179,3 +179,68 @@ def structured_meshes(subdivisions=4, grid=96, sampler_res=(50, 25)):
 
 STRUCTURED_CAMERA = dict(origin=(5.0, 3.0, 6.0), lookat=(0.0, 0.6, 0.0), vup=(0.0, 1.0, 0.0), fov=45.0,
                          aspect_ratio=float(np.float32(16.0) / np.float32(9.0)), aperture=0.0, focus_dist=10.0)
+
+
+def random_everything(seed, sampler_res=(16, 8)):
+    """A random small scene for differential testing: every primitive kind (spheres, free triangles, mesh
+    triangles with their own normals, an axis-aligned cuboid) paired at random with every material kind over
+    every texture kind, one to three lights (or none), any split type, samplable or unsamplable sky."""
+    rng = np.random.default_rng(seed)
+    sc = SceneDescription([abi.RT_SPLIT_SAH, abi.RT_SPLIT_MIDDLE, abi.RT_SPLIT_EQUAL_COUNTS][seed % 3])
+    ran_vecs, perm = pkg.ssml.perlin_tables(seed)
+    textures = [
+        sc.solid(rng.uniform(0.1, 0.95, 3)),
+        sc.lerp(rng.uniform(0.2, 1.0, 3), rng.uniform(0.0, 0.8, 3)),
+        sc.checkered(rng.uniform(0.5, 1.0, 3), rng.uniform(0.0, 0.4, 3)),
+        sc.perlin(ran_vecs, perm),
+        sc.image(rng.uniform(0.0, 1.0, (int(rng.integers(2, 9)), int(rng.integers(2, 17)), 3)).astype(np.float32)),
+    ]
+
+    def tex():
+        return textures[int(rng.integers(0, len(textures)))]
+
+    def material():
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return sc.lambertian(tex(), float(rng.uniform(0.3, 0.95)))
+        if k == 1:
+            return sc.reflect(tex(), float(rng.uniform(0.0, 0.5)))
+        if k == 2:
+            return sc.refract(tex(), float(rng.uniform(1.1, 2.0)))
+        if k == 3:
+            return sc.trowbridge_reitz(tex(), float(rng.uniform(0.1, 0.9)), tuple(rng.uniform(1.0, 2.5, 3)), float(rng.integers(0, 2)))
+        if k == 4:
+            return sc.lambertian(textures[0], 0.5)
+        return sc.trowbridge_reitz(textures[0], 0.4, (1.5, 1.5, 1.5), 0.0)
+
+    sc.sphere((0.0, -1000.0, 0.0), 1000.0, sc.lambertian(tex(), 0.8))
+    for _ in range(int(rng.integers(2, 7))):
+        sc.sphere(rng.uniform(-3, 3, 3) * (1, 0.3, 1) + (0, 0.7, 0), float(rng.uniform(0.2, 0.8)), material())
+    for _ in range(int(rng.integers(0, 5))):
+        p = rng.uniform(-3, 3, (3, 3)) * (1, 0.5, 1) + (0, 1.0, 0)
+        n = np.cross(p[1] - p[0], p[2] - p[0])
+        n = n / max(np.linalg.norm(n), 1e-9)
+        sc.triangle([tuple(q) for q in p], [tuple(n)] * 3, material())
+    if rng.integers(0, 2):
+        lo = rng.uniform(-2.5, 1.5, 3) * (1, 0.0, 1)
+        sc.aacuboid(tuple(lo), tuple(lo + rng.uniform(0.3, 1.0, 3)), material())
+    if rng.integers(0, 2):
+        v, f = icosphere(int(rng.integers(0, 2)))
+        centre, radius = rng.uniform(-2, 2, 3) * (1, 0.2, 1) + (0, 1.2, 0), float(rng.uniform(0.3, 0.7))
+        m = sc.mesh((v * np.float32(radius) + np.float32(centre)).astype(np.float32), v)
+        mat = material()
+        sc.mesh_triangles_bulk(m, f, f, np.full(len(f), mat, np.uint32))
+    for _ in range(int(rng.integers(0, 4))):
+        light = sc.emissive(sc.solid(rng.uniform(0.5, 1.0, 3)), float(rng.uniform(1.0, 8.0)))
+        if rng.integers(0, 2):
+            sc.sphere(rng.uniform(-3, 3, 3) * (1, 0.3, 1) + (0, 3.0, 0), float(rng.uniform(0.2, 0.6)), light)
+        else:
+            p = rng.uniform(-2, 2, (3, 3)) + (0, 3.5, 0)
+            n = np.cross(p[1] - p[0], p[2] - p[0])
+            n = n / max(np.linalg.norm(n), 1e-9)
+            sc.triangle([tuple(q) for q in p], [tuple(n)] * 3, light)
+    sky = [textures[1], textures[0], sc.solid((0.0, 0.0, 0.0))][int(rng.integers(0, 3))]
+    sc.set_sky(sky, sampler_res if rng.integers(0, 4) else (0, 0))
+    cam = dict(origin=tuple(rng.uniform(-1, 1, 3) * (3, 0.5, 1) + (0, 1.5, 7.0)), lookat=(0.0, 0.8, 0.0), vup=(0.0, 1.0, 0.0),
+               fov=float(rng.uniform(35, 75)), aspect_ratio=float(np.float32(16.0) / np.float32(9.0)), aperture=0.0, focus_dist=10.0)
+    return sc, cam
