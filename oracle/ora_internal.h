@@ -68,9 +68,11 @@ static inline float v3_mag_sq(vec3 a) { return v3_dot(a, a); }
 static inline float v3_mag(vec3 a) { return sqrtf(v3_dot(a, a)); }
 static inline vec3 v3_normalised(vec3 a) { return v3_divs(a, v3_mag(a)); }
 static inline vec3 v3_abs(vec3 a) { return v3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
-/* f32::min / f32::max: a NaN operand is ignored (P-hazard 13) */
-static inline float f_min(float a, float b) { return fminf(a, b); }
-static inline float f_max(float a, float b) { return fmaxf(a, b); }
+/* f32::min / f32::max: a NaN operand is ignored (P-hazard 13).  Written out instead of fminf/fmaxf because
+ * the sign of a +0/-0 tie is unspecified there (glibc returns the second argument, LLVM's x86 lowering of
+ * llvm.minnum/maxnum -- what rustc emits for f32::min/max -- the first): `a.max(b)` keeps `a` on a tie. */
+static inline float f_min(float a, float b) { return a != a ? b : (b < a ? b : a); }
+static inline float f_max(float a, float b) { return a != a ? b : (b > a ? b : a); }
 /* vec.rs:216-223 : x.max(y.max(z)) */
 static inline float v3_component_max(vec3 a) { return f_max(a.x, f_max(a.y, a.z)); }
 static inline vec3 v3_min_by_component(vec3 a, vec3 b) { return v3(f_min(a.x, b.x), f_min(a.y, b.y), f_min(a.z, b.z)); }

@@ -44,10 +44,18 @@ RT_FN float mag(V3 a) { return sqrtf(dot(a, a)); }
 RT_FN V3 normalised(V3 a) { return a / mag(a); }
 RT_FN V3 vabs(V3 a) { return V3{fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
 
-// f32::min / f32::max ignore a NaN operand (aabb.rs:31-56 relies on it); fminf/fmaxf do the same
-// on x86 and lower to v_min_f32 / v_max_f32 (IEEE mode) on gfx950.
+// f32::min / f32::max ignore a NaN operand (aabb.rs:31-56 relies on it).  On the device fminf/fmaxf lower
+// to v_min_f32 / v_max_f32 (IEEE mode), which do the same; everything they feed there is compared or
+// divided by later, where the sign of a +0/-0 tie cannot matter.  On the host (BVH bounds, which
+// rt_scene_get_nodes hands out) the tie is resolved the way rustc's f32::min/max resolve it on x86-64 --
+// LLVM's minnum/maxnum lowering keeps the FIRST operand -- rather than the way libm happens to.
+#if defined(__HIP_DEVICE_COMPILE__)
 RT_FN float fmin_(float a, float b) { return fminf(a, b); }
 RT_FN float fmax_(float a, float b) { return fmaxf(a, b); }
+#else
+RT_FN float fmin_(float a, float b) { return a != a ? b : (b < a ? b : a); }
+RT_FN float fmax_(float a, float b) { return a != a ? b : (b > a ? b : a); }
+#endif
 RT_FN float component_max(V3 a) { return fmax_(a.x, fmax_(a.y, a.z)); }
 RT_FN V3 min_by_component(V3 a, V3 b) { return V3{fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; }
 RT_FN V3 max_by_component(V3 a, V3 b) { return V3{fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; }
