@@ -240,6 +240,10 @@ int rt_camera_new(rt_camera *out, const float origin[3], const float lookat[3], 
  * acceleration/split.rs:78-210 do, builds the sky tables (textures/mod.rs:32-50,
  * statistics/distributions.rs:12-99), and lays everything out in the HBM of `device`. ---- */
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
+/* device = RT_DEVICE_NONE: Bvh::new on the host only.  rt_scene_counts / rt_scene_get_nodes /
+ * rt_scene_get_primitive_order / rt_scene_get_lights work; every call that would render or trace
+ * returns RT_ERR_NO_DEVICE (there is no CPU fallback). */
+#define RT_DEVICE_NONE (-1)
 void rt_scene_destroy(rt_scene *scene);
 
 /* introspection of what Bvh::new produced (for parity tests against the oracle) */

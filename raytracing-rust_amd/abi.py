@@ -28,6 +28,7 @@ RT_LAYOUT_FRAME, RT_LAYOUT_SHARD = range(2)
 RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS, RT_TUNE_SCHEDULE = range(4)
 
 NO_INDEX = 0xFFFFFFFFFFFFFFFF  # usize::MAX
+RT_DEVICE_NONE = -1  # rt_scene_create: Bvh::new on the host only (no GPU touched, nothing can be rendered)
 
 f32x3 = C.c_float * 3
 

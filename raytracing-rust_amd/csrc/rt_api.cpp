@@ -146,6 +146,10 @@ void rt_scene_destroy(rt_scene *s)
 {
 	if (!s)
 		return;
+	if (s->device == RT_DEVICE_NONE) { // host-only scene: nothing lives on a GPU
+		delete s;
+		return;
+	}
 	(void)hipSetDevice(s->device);
 	for (void *p : s->allocations)
 		(void)hipFree(p);
@@ -174,6 +178,18 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if (!desc || !out)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	*out = nullptr;
+	if (device == RT_DEVICE_NONE) { // Bvh::new only: the tree, the primitive order and the lights, no GPU touched
+		rt_scene *hs = new rt_scene();
+		hs->device = RT_DEVICE_NONE;
+		std::string herr;
+		const int hrc = build_host_scene(desc, hs->host, herr);
+		if (hrc != RT_OK) {
+			delete hs;
+			return fail(hrc, herr);
+		}
+		*out = hs;
+		return RT_OK;
+	}
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
 		return fail(RT_ERR_NO_DEVICE, "no HIP device: the rt_hip back end has no CPU fallback");
@@ -490,6 +506,8 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	int rc = shard_geometry(o, g);
 	if (rc != RT_OK)
 		return rc;
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): rendering needs a GPU, there is no CPU fallback");
 	if (o->render_method != RT_METHOD_NAIVE && o->render_method != RT_METHOD_MIS)
 		return fail(RT_ERR_INVALID_ARGUMENT, "unknown render method");
 	if (o->samples_per_pixel == 0 || o->samples_per_pixel >= (1ull << 32))
@@ -619,6 +637,8 @@ int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, flo
 {
 	if (!s || !camera || !o)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): this call needs a GPU, there is no CPU fallback");
 	uint64_t n_floats = 0;
 	int rc = rt_render_output_floats(o, &n_floats);
 	if (rc != RT_OK)
@@ -652,6 +672,8 @@ int rt_sample_image(rt_scene *s, const rt_camera *camera, const rt_render_opts *
 {
 	if (!s || !camera || !o)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): this call needs a GPU, there is no CPU fallback");
 	uint64_t n_floats = 0;
 	int rc = rt_render_output_floats(o, &n_floats);
 	if (rc != RT_OK)
@@ -960,6 +982,8 @@ static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *ob
 {
 	if (!s || !rays || !out)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): this call needs a GPU, there is no CPU fallback");
 	if (n == 0)
 		return RT_OK;
 	if (object_index)

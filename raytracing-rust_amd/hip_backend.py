@@ -86,7 +86,8 @@ def _pack_rays(origins, directions):
 
 
 class HipScene:
-    """Bvh::new(primitives, sky, split_type) + upload to the HBM of `device`."""
+    """Bvh::new(primitives, sky, split_type) + upload to the HBM of `device`
+    (device=abi.RT_DEVICE_NONE: the host-side tree only; rendering then raises RT_ERR_NO_DEVICE)."""
 
     def __init__(self, scene_description, device=0):
         self._desc = scene_description.desc()
