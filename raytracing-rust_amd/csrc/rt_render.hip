@@ -69,6 +69,10 @@ constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase
 #define RT_NODE_STEPS_PER_VOTE 16
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
+#ifndef RT_FULL_WAVES
+#define RT_FULL_WAVES 3 // waves per SIMD of the full-feature variants under the coarse schedule (a few dozen spilled
+                        // registers, still faster than 2: all_materials naive 131 -> 109 ms, MIS 292 -> 275 ms); fine keeps 2
+#endif
 #ifndef RT_SPHERES_WAVES
 #define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to
 #endif
@@ -100,11 +104,11 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 // Workgroup size and register budget per feature set.  Spheres-only kernels fit 128 VGPRs = 4 waves per
 // SIMD, but three 256-thread workgroups with a 41 KB sky table each are all the LDS of a CU holds, so
 // they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1).  The larger
-// variants are register-limited to 3 (simple) or 2 (full) waves per SIMD and keep 256 threads.
-template <class F> struct KernelShape {
+// variants are register-limited to 3 waves per SIMD (full-feature kernels under the fine schedule: 2) and keep 256 threads.
+template <class F, bool FINE = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr int block = spheres_only ? 512 : 256;
-	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? 2 : (spheres_only ? RT_SPHERES_WAVES : 3);
+	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? 2 : RT_FULL_WAVES) : (spheres_only ? RT_SPHERES_WAVES : 3);
 };
 
 #ifdef RT_STATS
@@ -113,7 +117,7 @@ __device__ unsigned long long g_stats[32];
 #endif
 
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
-__global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_simd) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
+__global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter)
 {
@@ -741,6 +745,18 @@ __global__ __launch_bounds__(KernelShape<F>::block, KernelShape<F>::waves_per_si
 					do_shade(std::integral_constant<int, 2>{});
 #endif
 			}
+#if RT_PQ_SPLIT
+			if (METHOD == 1) {
+				// With the two super-phases above no walk is ever pending at the end of an iteration: the ray and
+				// the walk state are dead here.  Saying so keeps them out of the loop-carried registers.
+				ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
+				best_t = 0.0f;
+				best_prim = kNoPrim;
+				node = kRefDone;
+				sp = 0;
+				any_hit = false;
+			}
+#endif
 		}
 	}
 

@@ -7,9 +7,13 @@ import scenes
 abi = pkg.abi
 name = sys.argv[1]
 W, H, SPP, method, reps = (int(x) for x in sys.argv[2:7])
-ls = scenes.load_ssml(name)
-g = hb.HipScene(ls.scene)
-cam = hb.camera_new(**ls.camera_params)
+if name == "all_materials":
+    g = hb.HipScene(scenes.all_materials())
+    cam = hb.camera_new(**scenes.ALL_MATERIALS_CAMERA)
+else:
+    ls = scenes.load_ssml(name)
+    g = hb.HipScene(ls.scene)
+    cam = hb.camera_new(**ls.camera_params)
 opts = abi.default_render_opts(W, H, SPP, method=method, seed=1)
 for _ in range(reps):
     img, rays = g.render(cam, opts)
