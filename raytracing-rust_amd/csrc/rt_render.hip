@@ -73,6 +73,9 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #define RT_FULL_WAVES 3 // waves per SIMD of the full-feature variants under the coarse schedule (a few dozen spilled
                         // registers, still faster than 2: all_materials naive 131 -> 109 ms, MIS 292 -> 275 ms); fine keeps 2
 #endif
+#ifndef RT_SPHERES_BLOCK
+#define RT_SPHERES_BLOCK 512
+#endif
 #ifndef RT_SPHERES_WAVES
 #define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to
 #endif
@@ -107,7 +110,7 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 // variants are register-limited to 3 waves per SIMD (full-feature kernels under the fine schedule: 2) and keep 256 threads.
 template <class F, bool FINE = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
-	static constexpr int block = spheres_only ? 512 : 256;
+	static constexpr int block = spheres_only ? RT_SPHERES_BLOCK : 256;
 	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? 2 : RT_FULL_WAVES) : (spheres_only ? RT_SPHERES_WAVES : 3);
 };
 
