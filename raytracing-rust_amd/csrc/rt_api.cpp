@@ -20,7 +20,7 @@
 
 namespace rt {
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block);
-uint32_t render_block_threads(int feature_set);
+uint32_t render_block_threads(int feature_set, bool fine);
 hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
@@ -583,13 +583,13 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	const bool scene_lds = !fine && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
 	P.scene_in_lds = scene_lds ? 1u : 0u;
 	bool sky_lds = false;
-	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, render_block_threads(s->feature_set) / 64u);
+	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, render_block_threads(s->feature_set, fine) / 64u);
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
 	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, render_block_threads(s->feature_set) / 64u);
+		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, render_block_threads(s->feature_set, fine) / 64u);
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
 		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
@@ -603,7 +603,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
-	const uint64_t blocks_needed = ((uint64_t)P.n_items + render_block_threads(s->feature_set) - 1) / render_block_threads(s->feature_set);
+	const uint64_t blocks_needed = ((uint64_t)P.n_items + render_block_threads(s->feature_set, fine) - 1) / render_block_threads(s->feature_set, fine);
 	if (n_blocks > blocks_needed)
 		n_blocks = blocks_needed ? blocks_needed : 1;
 

@@ -73,6 +73,10 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #define RT_FULL_WAVES 3 // waves per SIMD of the full-feature variants under the coarse schedule (a few dozen spilled
                         // registers, still faster than 2: all_materials naive 131 -> 109 ms, MIS 292 -> 275 ms); fine keeps 2
 #endif
+#ifndef RT_SIMPLE_COARSE_WAVES
+#define RT_SIMPLE_COARSE_WAVES 4 // simple (triangles + lights) variants under the coarse schedule: 128 VGPRs with 20-40 spilled
+                                 // registers beat 168 VGPRs at 3 waves (overshadowed MIS 212 -> 196 ms, 1 000 triangles 43 -> 33 ms)
+#endif
 #ifndef RT_SPHERES_BLOCK
 #define RT_SPHERES_BLOCK 512
 #endif
@@ -106,12 +110,15 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 
 // Workgroup size and register budget per feature set.  Spheres-only kernels fit 128 VGPRs = 4 waves per
 // SIMD, but three 256-thread workgroups with a 41 KB sky table each are all the LDS of a CU holds, so
-// they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1).  The larger
-// variants are register-limited to 3 waves per SIMD (full-feature kernels under the fine schedule: 2) and keep 256 threads.
+// they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1); so do the simple
+// variants under the coarse schedule.  Fine-schedule and full-feature kernels keep 256 threads at 3 waves
+// per SIMD (full-feature fine: 2).
 template <class F, bool FINE = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
-	static constexpr int block = spheres_only ? RT_SPHERES_BLOCK : 256;
-	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? 2 : RT_FULL_WAVES) : (spheres_only ? RT_SPHERES_WAVES : 3);
+	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
+	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? 2 : RT_FULL_WAVES)
+	                                      : (spheres_only ? RT_SPHERES_WAVES : (FINE ? 3 : RT_SIMPLE_COARSE_WAVES));
+	static constexpr int block = spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256);
 };
 
 #ifdef RT_STATS
@@ -947,7 +954,14 @@ extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
 }
 #endif
 
-uint32_t render_block_threads(int feature_set) { return feature_set == 0 ? (uint32_t)KernelShape<Feat<false, false, false, false>>::block : 256u; }
+uint32_t render_block_threads(int feature_set, bool fine)
+{
+	if (feature_set == 0)
+		return (uint32_t)KernelShape<Feat<false, false, false, false>>::block;
+	if (feature_set == 1)
+		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::block : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::block;
+	return 256u;
+}
 
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block)
 {
@@ -1007,7 +1021,7 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess)
 		return e;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set), lds_bytes);
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set, fine), lds_bytes);
 }
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
@@ -1017,7 +1031,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
 	return hipGetLastError();
 }
 
