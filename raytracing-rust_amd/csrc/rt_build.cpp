@@ -13,9 +13,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 
 namespace rt {
 namespace {
@@ -61,13 +63,32 @@ inline uint64_t as_usize(float f)
 	return (uint64_t)f;
 }
 
+// independent per-element host loops over millions of primitives: contiguous chunks on a few threads
+template <class Fn> void parallel_for(uint64_t n, Fn fn)
+{
+	constexpr uint64_t kMinChunk = 65536;
+	const uint64_t chunks = std::min<uint64_t>(16, (n + kMinChunk - 1) / kMinChunk);
+	if (chunks <= 1) {
+		fn(0, n);
+		return;
+	}
+	std::vector<std::future<void>> pending;
+	for (uint64_t c = 1; c < chunks; ++c)
+		pending.push_back(std::async(std::launch::async, [=, &fn] { fn(n * c / chunks, n * (c + 1) / chunks); }));
+	fn(0, n / chunks);
+	for (auto &f : pending)
+		f.get();
+}
+
 class Builder {
   public:
 	Builder(int split_type, std::vector<HostNode> &nodes) : split_type_(split_type), nodes_(nodes) {}
 
-	// Bvh::build_bvh  mod.rs:97-160 (node pushed before its children: preorder numbering)
-	uint64_t build(PrimInfo *info, uint64_t n, uint64_t offset)
+	// One node of Bvh::build_bvh (mod.rs:97-160): push the node, decide leaf or split.  Returns the node's
+	// index; `mid` = 0 means leaf, otherwise the children are info[0, mid) and info[mid, n).
+	uint64_t node_and_split(PrimInfo *info, uint64_t n, uint64_t offset, uint64_t &mid)
 	{
+		mid = 0;
 		Bounds bounds;
 		for (uint64_t i = 0; i < n; ++i)
 			bounds.merge(info[i].min, info[i].max);
@@ -90,7 +111,15 @@ class Builder {
 		if (std::fabs(axis_of(axis, cb.min) - axis_of(axis, cb.max)) < 100.0f * kF32Epsilon)
 			return node_index; // all centroids coincide on the widest axis: one leaf
 
-		const uint64_t mid = split(bounds, cb, axis, info, n);
+		mid = split(bounds, cb, axis, info, n);
+		return node_index;
+	}
+
+	// Bvh::build_bvh, sequential (node pushed before its children: preorder numbering)
+	uint64_t build(PrimInfo *info, uint64_t n, uint64_t offset)
+	{
+		uint64_t mid;
+		const uint64_t node_index = node_and_split(info, n, offset, mid);
 		if (mid == 0)
 			return node_index;
 		const uint64_t c0 = build(info, mid, offset);
@@ -99,6 +128,46 @@ class Builder {
 		nodes_[node_index].child[1] = (int64_t)c1;
 		return node_index;
 	}
+
+	// The same tree with the two subtrees of every large node built concurrently.  A subtree touches only its own
+	// slice of `info` and is built into its own vector with local indices; splicing [node][left][right] and
+	// shifting the child indices restores the preorder numbering, so the result is the sequential one bit for bit.
+	static void build_concurrent(int split_type, PrimInfo *info, uint64_t n, uint64_t offset, std::vector<HostNode> &out, int depth)
+	{
+		Builder b(split_type, out);
+		static const int max_depth = std::getenv("RT_HIP_BUILD_DEPTH") ? std::atoi(std::getenv("RT_HIP_BUILD_DEPTH")) : kConcurrentDepth;
+		if (n < kConcurrentMin || depth >= max_depth) {
+			b.build(info, n, offset);
+			return;
+		}
+		uint64_t mid;
+		b.node_and_split(info, n, offset, mid);
+		if (mid == 0)
+			return;
+		std::vector<HostNode> left, right;
+		left.reserve(2 * mid);
+		right.reserve(2 * (n - mid));
+		std::future<void> other = std::async(std::launch::async, [&] { build_concurrent(split_type, info, mid, offset, left, depth + 1); });
+		build_concurrent(split_type, info + mid, n - mid, offset + mid, right, depth + 1);
+		other.get();
+		const int64_t base_left = (int64_t)out.size(), base_right = base_left + (int64_t)left.size();
+		out[(size_t)base_left - 1].child[0] = base_left;
+		out[(size_t)base_left - 1].child[1] = base_right;
+		out.reserve(out.size() + left.size() + right.size());
+		for (int side = 0; side < 2; ++side) {
+			const std::vector<HostNode> &sub = side == 0 ? left : right;
+			const int64_t base = side == 0 ? base_left : base_right;
+			for (HostNode nd : sub) {
+				if (nd.child[0] >= 0) {
+					nd.child[0] += base;
+					nd.child[1] += base;
+				}
+				out.push_back(nd);
+			}
+		}
+	}
+	static constexpr uint64_t kConcurrentMin = 32768; // smaller subtrees are not worth a thread
+	static constexpr int kConcurrentDepth = 5;        // up to 32 subtrees in flight
 
   private:
 	// the partition! macro  split.rs:8-32
@@ -298,6 +367,16 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		return RT_ERR_UNSUPPORTED;
 	}
 
+	// RT_HIP_BUILD_TIMING=1: phase times on stderr
+	const bool timing = std::getenv("RT_HIP_BUILD_TIMING") != nullptr;
+	auto t_prev = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!timing)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[rt_build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+		t_prev = now;
+	};
 	// ---- textures ----
 	hs.textures.resize(d->n_textures);
 	hs.tex_images.resize(d->n_textures);
@@ -414,10 +493,11 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		info[i].center = 0.5f * (mn + mx);
 	}
 
+	lap("validate + fetch geometry");
 	// ---- Bvh::new ----
 	hs.nodes.clear();
 	hs.nodes.reserve(2 * n);
-	Builder(d->split_type, hs.nodes).build(info.data(), n, 0);
+	Builder::build_concurrent(d->split_type, info.data(), n, 0, hs.nodes, 0);
 	hs.primitive_order.resize(n);
 	for (uint64_t i = 0; i < n; ++i)
 		hs.primitive_order[i] = info[i].index; // sort_by_indices: slot i <- primitives[info[i].index]
@@ -427,10 +507,12 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			hs.lights.push_back(i);
 	hs.dev_lights.assign(hs.lights.begin(), hs.lights.end());
 
+	lap("Bvh::new");
 	// ---- device primitive records in slot order ----
 	hs.dev_prims.resize(n);
 	hs.dev_shade.resize(hs.has_triangles ? n : 1);
-	for (uint64_t slot = 0; slot < n; ++slot) {
+	parallel_for(n, [&](uint64_t slot_begin, uint64_t slot_end) {
+	for (uint64_t slot = slot_begin; slot < slot_end; ++slot) {
 		const rt_primitive_desc &p = d->primitives[hs.primitive_order[slot]];
 		DevPrim &o = hs.dev_prims[slot];
 		std::memset(&o, 0, sizeof o);
@@ -457,7 +539,9 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		const uint32_t meta = type | (p.material << 2);
 		std::memcpy(&o.a[3], &meta, 4);
 	}
+	});
 
+	lap("device primitive records");
 	// ---- BFS-leaf rank: the order get_intersection_candidates lists leaves in (mod.rs:199-224) ----
 	hs.prim_rank.assign(n, 0);
 	{
@@ -477,6 +561,7 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		}
 	}
 
+	lap("BFS-leaf rank");
 	// ---- two-child device nodes; inner nodes renumbered in preorder ----
 	const HostNode &root = hs.nodes[0];
 	std::memcpy(hs.root_min, root.min, sizeof hs.root_min);
@@ -503,31 +588,33 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 				dev_index[i] = n_inner++;
 		hs.dev_nodes.resize(n_inner);
 		hs.root_ref = 0;
-		// depth of the inner-node tree (stack entries needed by the depth-first walk)
-		std::vector<std::pair<uint64_t, uint32_t>> work;
-		work.push_back({0, 1});
-		while (!work.empty()) {
-			const auto [id, depth] = work.back();
-			work.pop_back();
-			const HostNode &hn = hs.nodes[id];
-			max_depth = std::max(max_depth, depth);
-			DevNode &dn = hs.dev_nodes[(size_t)dev_index[id]];
-			dn.pad0 = dn.pad1 = 0;
-			for (int c = 0; c < 2; ++c) {
-				const HostNode &ch = hs.nodes[(size_t)hn.child[c]];
-				float *mn = c == 0 ? dn.c0min : dn.c1min, *mx = c == 0 ? dn.c0max : dn.c1max;
-				std::memcpy(mn, ch.min, 12);
-				std::memcpy(mx, ch.max, 12);
-				uint32_t ref;
-				if (ch.child[0] >= 0) {
-					ref = (uint32_t)dev_index[(size_t)hn.child[c]];
-					work.push_back({(uint64_t)hn.child[c], depth + 1});
-				} else {
-					ref = leaf_ref(ch);
-				}
-				(c == 0 ? dn.c0 : dn.c1) = ref;
-			}
+		// depth of the inner-node tree (stack entries needed by the depth-first walk): children follow their
+		// parent in preorder, so one forward pass settles every level
+		std::vector<uint32_t> level(hs.nodes.size(), 0u);
+		level[0] = 1;
+		for (size_t i = 0; i < hs.nodes.size(); ++i) {
+			const HostNode &hn = hs.nodes[i];
+			if (hn.child[0] < 0)
+				continue;
+			max_depth = std::max(max_depth, level[i]);
+			level[(size_t)hn.child[0]] = level[(size_t)hn.child[1]] = level[i] + 1;
 		}
+		parallel_for(hs.nodes.size(), [&](uint64_t begin, uint64_t end) {
+			for (uint64_t id = begin; id < end; ++id) {
+				const HostNode &hn = hs.nodes[id];
+				if (hn.child[0] < 0)
+					continue;
+				DevNode &dn = hs.dev_nodes[(size_t)dev_index[id]];
+				dn.pad0 = dn.pad1 = 0;
+				for (int c = 0; c < 2; ++c) {
+					const HostNode &ch = hs.nodes[(size_t)hn.child[c]];
+					float *mn = c == 0 ? dn.c0min : dn.c1min, *mx = c == 0 ? dn.c0max : dn.c1max;
+					std::memcpy(mn, ch.min, 12);
+					std::memcpy(mx, ch.max, 12);
+					(c == 0 ? dn.c0 : dn.c1) = ch.child[0] >= 0 ? (uint32_t)dev_index[(size_t)hn.child[c]] : leaf_ref(ch);
+				}
+			}
+		});
 	} else {
 		hs.dev_nodes.resize(1);
 		std::memset(hs.dev_nodes.data(), 0, sizeof(DevNode));
@@ -539,6 +626,7 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		return RT_ERR_UNSUPPORTED;
 	}
 
+	lap("device nodes");
 	// ---- Sky::new  sky.rs:22-39 ----
 	const uint64_t rx = d->sky.sampler_res_x, ry = d->sky.sampler_res_y;
 	hs.sky_cdf.clear();

@@ -32,7 +32,7 @@ def test_random_scenes(hb, O, seed):
 def test_sizes_and_split_types(hb, O, split):
     for n in (1, 2, 3, 4, 5, 8, 13, 64, 255, 256, 257, 1000, 20000):
         _same_tree(hb, O, scenes.random_spheres(n, seed=n + split, split_type=split, emissive_every=7))
-    for n in (1, 2, 5, 12, 300, 50000):
+    for n in (1, 2, 5, 12, 300, 50000, 250000):  # >= 32768 primitives: subtrees are built concurrently (rt_build.cpp)
         _same_tree(hb, O, scenes.random_triangle_mesh(n, seed=n + split, extent=4.0, edge=0.4, split_type=split,
                                                       emissive_every=11, sampler_res=(4, 4)))
 
