@@ -122,8 +122,14 @@ template <class F, bool FINE = false> struct KernelShape {
 };
 
 #ifdef RT_STATS
+// section timing of the coarse schedule (diagnostic build): wave wall-clock cycles per section, lane 0
+#define RT_SECTION(k) do { const unsigned long long now_ = wall_clock64(); st_sect[(k)] += now_ - st_mark; st_mark = now_; } while (0)
+#else
+#define RT_SECTION(k) do { } while (0)
+#endif
+#ifdef RT_STATS
 // diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/gpu_stats_probe.py
-__device__ unsigned long long g_stats[32];
+__device__ unsigned long long g_stats[64];
 #endif
 
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
@@ -586,6 +592,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 
 #ifdef RT_STATS
 	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
+	unsigned long long st_sect[9] = {}, st_mark = wall_clock64();
 	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
@@ -727,12 +734,16 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 				}
 			}
 #endif
+			RT_SECTION(0); // vote + work acquisition
 			if (!run_light) {
 				if (ph == PH_GEN)
 					do_gen();
+				RT_SECTION(1);
 				walk_closest_pending();
+				RT_SECTION(2);
 				if (ph == PH_SHADE)
 					do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
+				RT_SECTION(3);
 			} else {
 				LightCtx L; // loop-local: see LightCtx above
 				L.l_wi = v3s(0.0f);
@@ -744,15 +755,20 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 				sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
 				if (ph == PH_LIGHT)
 					do_light(L, sray);
+				RT_SECTION(4);
 				walk_shadow_pending(L, sray);
+				RT_SECTION(5);
 				if (ph == PH_SCATTER)
 					do_scatter(L, sray);
+				RT_SECTION(6);
 #if RT_PQ_SPLIT
 				// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
 				// the other super-phase only ever holds primary lanes and neither arm runs half empty
 				walk_closest_pending();
+				RT_SECTION(7);
 				if (ph == PH_SHADE)
 					do_shade(std::integral_constant<int, 2>{});
+				RT_SECTION(8);
 #endif
 			}
 #if RT_PQ_SPLIT
@@ -778,6 +794,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	atomicAdd(&g_stats[24], st_lane_dead[1]);
 	atomicAdd(&g_stats[25], st_lane_dead[2]);
 	if (lane == 0u) {
+		for (int k = 0; k < 9; ++k)
+			atomicAdd(&g_stats[40 + k], st_sect[k]);
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
 		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);
 		atomicAdd(&g_stats[4], st_gen);
@@ -947,7 +965,7 @@ extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess)
 		return -1;
 	if (reset) {
-		unsigned long long z[32] = {};
+		unsigned long long z[64] = {};
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z);
 	}
 	return 0;

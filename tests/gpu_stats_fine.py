@@ -6,7 +6,7 @@ g = hb.HipScene(scenes.random_triangle_mesh(int(sys.argv[1]) if len(sys.argv) > 
 names = ["GEN", "NODE(x8)", "LEAF", "SHADE", "LIGHT", "SCATTER"]
 for method in (0, 1):
     o = abi.default_render_opts(1920, 1080, 8, method=method)
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 64)()
     hb.lib().rt_debug_stats(out, 1)
     g.render(cam, o)
     hb.lib().rt_debug_stats(out, 1)

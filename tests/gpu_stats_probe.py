@@ -6,11 +6,15 @@ import scenes
 for name in ("rtweekend1", "overshadowed"):
     ls = scenes.load_ssml(name); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
     o = abi.default_render_opts(1920, 1080, 64)
-    out = (C.c_ulonglong * 32)()
+    out = (C.c_ulonglong * 64)()
     hb.lib().rt_debug_stats(out, 1)
     img, rays = g.render(cam, o)
     hb.lib().rt_debug_stats(out, 1)
     ti, ta, li, la, gen = out[0], out[1], out[2], out[3], out[4]
+    sect = [out[40 + k] for k in range(9)]
+    tot = max(1, sum(sect))
+    names = ["vote+claim", "P:gen", "P:walk", "P:shade", "Q:light", "Q:shadow walk", "Q:scatter", "Q:walk", "Q:shade"]
+    print("   wave wall-clock share: " + "  ".join(f"{nm} {100*v/tot:.1f}%" for nm, v in zip(names, sect)))
     n = 1920 * 1080 * 64
     print(f"{name}: TRACE iters {ti} avg active {ta/ti:.1f}/64 (gen lanes/iter {gen/ti:.1f}) | LIGHT iters {li} avg active {la/li:.1f}/64 | "
           f"per sample: trace-lane-steps {ta/n:.2f} light-lane-steps {la/n:.2f}; wave-iters per 64 samples: trace {ti*64/n:.2f} light {li*64/n:.2f}")
