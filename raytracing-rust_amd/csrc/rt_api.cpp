@@ -247,6 +247,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
 	const float *d_sky = nullptr;
 	if ((rc = upload(s, h.sky_cdf.data(), h.sky_cdf.size(), &d_sky)) != RT_OK) return bail(rc);
+	const uint8_t *d_guide = nullptr;
+	if ((rc = upload(s, h.sky_guide.data(), h.sky_guide.size(), &d_guide)) != RT_OK) return bail(rc);
 	{
 		// tiny scenes: one packed copy of every array, staged into LDS by the render kernel.  Built here
 		// (not in rt_build.cpp) because the texture records must already hold their device pointers.
@@ -290,6 +292,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	D.sky.res_y = h.sky.sampler_res_y;
 	D.sky.row_cdf = d_sky;
 	D.sky.marginal_cdf = d_sky + (size_t)h.sky.sampler_res_y * (h.sky.sampler_res_x + 1u);
+	D.sky.guide = h.sky_guide_k ? d_guide : nullptr;
+	D.sky.guide_k = h.sky_guide_k;
 
 	void *p = nullptr;
 	if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc work counter"));
@@ -574,7 +578,8 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.prune = prune ? 1 : 0;
 
 	const bool samplable = (s->dev.sky.res_x | s->dev.sky.res_y) != 0u;
-	const size_t sky_bytes = samplable ? ((size_t)s->dev.sky.res_y * (s->dev.sky.res_x + 1u) + s->dev.sky.res_y + 1u) * 4 : 0;
+	const size_t sky_bytes = samplable ? ((size_t)s->dev.sky.res_y * (s->dev.sky.res_x + 1u) + s->dev.sky.res_y + 1u) * 4 +
+	                                         (size_t)(s->dev.sky.res_y + 1u) * s->dev.sky.guide_k : 0;
 	// Sky CDF tables in LDS (next to the traversal stacks) or left in global memory: LDS only while
 	// it does not cost resident workgroups.  Tiny trees: 41 KB tables + 1-2 KB stacks still fit 3
 	// workgroups per CU, the register limit.  Deep trees: the stacks alone are tens of KB and the

@@ -659,6 +659,38 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			y_values[r] = row_sum;
 		}
 		make_cdf(y_values.data(), ry, hs.sky_cdf.data() + ry * (rx + 1));
+
+		// guide tables (rt_types.h DevSky): only for tables the byte entries can index and whose CDFs are
+		// finite and non-decreasing (then a rightward scan from the guide finds the binary search's index)
+		hs.sky_guide.clear();
+		hs.sky_guide_k = 0;
+		bool usable = rx <= 254 && ry <= 254;
+		for (float v : hs.sky_cdf)
+			usable = usable && std::isfinite(v);
+		for (uint64_t r = 0; r <= ry && usable; ++r) {
+			const float *cdf = hs.sky_cdf.data() + r * (rx + 1);
+			const uint64_t len = (r < ry ? rx : ry) + 1;
+			for (uint64_t i = 1; i < len; ++i)
+				usable = usable && cdf[i - 1] <= cdf[i];
+		}
+		if (usable) {
+			uint32_t K = 16;
+			while (K < std::max(rx, ry) && K < 256)
+				K *= 2;
+			hs.sky_guide_k = K;
+			hs.sky_guide.assign((size_t)(ry + 1) * K, 0);
+			for (uint64_t r = 0; r <= ry; ++r) {
+				const float *cdf = hs.sky_cdf.data() + r * (rx + 1);
+				const uint64_t len = (r < ry ? rx : ry) + 1; // entries 0..n
+				uint64_t first = 0;
+				for (uint32_t k = 0; k < K; ++k) {
+					const float threshold = (float)k / (float)K; // exact
+					while (first < len && cdf[first] <= threshold)
+						++first; // upper bound: first index with cdf > threshold
+					hs.sky_guide[r * K + k] = (uint8_t)first;
+				}
+			}
+		}
 	}
 	return RT_OK;
 }

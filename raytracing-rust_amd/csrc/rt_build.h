@@ -38,6 +38,8 @@ struct HostScene {
 	std::vector<std::vector<float>> tex_perlin_vecs;
 	std::vector<std::vector<uint32_t>> tex_perlin_perm;
 	std::vector<float> sky_cdf;                  // rows (res_y * (res_x+1)) then marginal (res_y+1)
+	std::vector<uint8_t> sky_guide;              // (res_y+1) rows of sky_guide_k upper-bound indices (rt_types.h DevSky)
+	uint32_t sky_guide_k = 0;
 	rt_sky_desc sky;
 	float root_min[3], root_max[3];
 	uint32_t stack_depth = 2;

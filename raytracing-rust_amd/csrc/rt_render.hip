@@ -153,13 +153,24 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 		for (uint32_t i = threadIdx.x; i < n_all; i += blockDim.x)
 			lds_sky[i] = S.sky.row_cdf[i]; // marginal follows the rows in the same allocation
 		__syncthreads();
+		sky_words = (n_all + 3u) & ~3u;
+		// ... and the guide tables behind them (a multiple of 16 bytes: guide_k is a power of two >= 16)
+		const uint32_t guide_words = (S.sky.res_y + 1u) * S.sky.guide_k / 4u;
+		uint32_t *lds_guide = lds + sky_words;
+		const uint32_t *src_guide = reinterpret_cast<const uint32_t *>(S.sky.guide);
+		for (uint32_t i = threadIdx.x; i < guide_words; i += blockDim.x)
+			lds_guide[i] = src_guide[i];
+		__syncthreads();
 		T.row_cdf = lds_sky;
 		T.marginal_cdf = lds_sky + n_rows;
-		sky_words = (n_all + 3u) & ~3u;
+		T.guide = reinterpret_cast<const uint8_t *>(lds_guide);
+		sky_words += guide_words;
 	} else {
 		T.row_cdf = S.sky.row_cdf;
 		T.marginal_cdf = S.sky.marginal_cdf;
+		T.guide = S.sky.guide;
 	}
+	T.guide_k = S.sky.guide_k;
 	// ---- tiny scenes (coarse schedule only): stage the whole scene into LDS, so the dependent loads
 	// of a walk (node -> primitive -> material -> texture) pay LDS latency instead of L1/L2 latency ----
 	uint32_t blob_words = 0;
@@ -987,6 +998,7 @@ size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_
 	if (sky_lds) {
 		const uint32_t n_all = S.sky.res_y * (S.sky.res_x + 1u) + S.sky.res_y + 1u;
 		words += (n_all + 3u) & ~3u;
+		words += (S.sky.res_y + 1u) * S.sky.guide_k / 4u;
 	}
 	words += (size_t)waves_per_block * S.stack_depth * kStackStride;
 	return words * sizeof(uint32_t);

@@ -163,19 +163,28 @@ template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &
 
 // ---- statistics/distributions.rs ----
 // Distribution1D::sample :51-72 over a cdf of n+1 entries
-__device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, rt_rng &rng)
+// `guide` (may be null; wave-uniform): guide_k upper-bound indices for this cdf, see DevSky in rt_types.h
+__device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, const uint8_t *guide, uint32_t guide_k, rt_rng &rng)
 {
 	const float num = rt_rng_f32(&rng);
-	uint32_t first = 0;
-	uint32_t len = n + 1;
-	while (len > 0) {
-		const uint32_t half = len >> 1;
-		const uint32_t middle = first + half;
-		if (cdf[middle] <= num) {
-			first = middle + 1;
-			len -= half + 1;
-		} else {
-			len = half;
+	uint32_t first;
+	if (guide != nullptr) {
+		// the upper bound of num lies at or right of the upper bound of floor(num * K) / K
+		first = guide[(uint32_t)(num * (float)guide_k)];
+		while (first <= n && cdf[first] <= num)
+			++first;
+	} else {
+		first = 0;
+		uint32_t len = n + 1;
+		while (len > 0) {
+			const uint32_t half = len >> 1;
+			const uint32_t middle = first + half;
+			if (cdf[middle] <= num) {
+				first = middle + 1;
+				len -= half + 1;
+			} else {
+				len = half;
+			}
 		}
 	}
 	const uint32_t v = first - 1u; // cdf[0] = 0 <= num, so first >= 1
@@ -185,6 +194,8 @@ __device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, 
 struct SkyTables {
 	const float *row_cdf;      // [res_y][res_x + 1]
 	const float *marginal_cdf; // [res_y + 1]
+	const uint8_t *guide;      // [res_y + 1][guide_k] or null
+	uint32_t guide_k;
 };
 
 __device__ __forceinline__ bool sky_can_sample(const DevScene &S) { return (S.sky.res_x | S.sky.res_y) != 0u; } // sky.rs:61-63
@@ -217,8 +228,9 @@ __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, 
 __device__ __forceinline__ V3 sky_sample(const DevScene &S, const SkyTables &T, rt_rng &rng)
 {
 	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
-	const uint32_t sv = dist1d_sample(T.marginal_cdf, ry, rng);
-	const uint32_t su = dist1d_sample(T.row_cdf + (size_t)sv * (rx + 1u), rx, rng);
+	const bool guided = T.guide_k != 0u;
+	const uint32_t sv = dist1d_sample(T.marginal_cdf, ry, guided ? T.guide + (size_t)ry * T.guide_k : nullptr, T.guide_k, rng);
+	const uint32_t su = dist1d_sample(T.row_cdf + (size_t)sv * (rx + 1u), rx, guided ? T.guide + (size_t)sv * T.guide_k : nullptr, T.guide_k, rng);
 	const float u = next_float((float)su + rt_rng_f32(&rng)) / (float)rx;
 	const float v = next_float((float)sv + rt_rng_f32(&rng)) / (float)ry;
 	const float phi = u * 2.0f * kPi;

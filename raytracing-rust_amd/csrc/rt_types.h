@@ -85,6 +85,12 @@ struct DevSky {
 	uint32_t res_x, res_y;     // (0,0): not samplable
 	const float *row_cdf;      // res_y * (res_x+1)
 	const float *marginal_cdf; // res_y + 1
+	// Guide tables for the CDF inversions (0 = none): guide[r * guide_k + k] is the upper-bound index of
+	// k / guide_k in row r (row res_y = the marginal).  A search starts there and steps right -- the
+	// same index Distribution1D::sample's binary search returns (distributions.rs:51-72), in about
+	// three dependent reads instead of seven.  guide_k is a power of two, so (uint)(num * guide_k) is exact.
+	const uint8_t *guide;      // (res_y + 1) * guide_k
+	uint32_t guide_k, pad_guide;
 };
 
 struct DevScene {
