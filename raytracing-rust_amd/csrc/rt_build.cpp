@@ -426,7 +426,13 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		o.param = m.param;
 		o.ior[0] = m.ior[0]; o.ior[1] = m.ior[1]; o.ior[2] = m.ior[2];
 		o.metallic = m.metallic;
-		o.pad = 0;
+		o.pad[0] = o.pad[1] = 0;
+		const DevTexture &t = hs.textures[m.texture];
+		o.tex_type = t.type;
+		for (int k = 0; k < 3; ++k) {
+			o.tex_c1[k] = t.c1[k];
+			o.tex_c2[k] = t.c2[k];
+		}
 	}
 	if (d->sky.texture >= d->n_textures || d->sky.material >= d->n_materials) {
 		err = "sky texture/material index out of range";

@@ -161,6 +161,21 @@ template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &
 	return v3s(1.0f);
 }
 
+// the texture of material record `m`: SolidColour and Lerp are answered from the copy inside the record
+template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point)
+{
+	const int type = m.tex_type;
+	if (type == 1)
+		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
+	if (type == 3) {
+		const float tt = direction.z * 0.5f + 0.5f;
+		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]) * tt + v3(m.tex_c2[0], m.tex_c2[1], m.tex_c2[2]) * (1.0f - tt);
+	}
+	if (!F::ctex)
+		return v3s(1.0f); // unreachable: see texture_colour
+	return texture_colour<F>(S, m.texture, direction, point);
+}
+
 // ---- statistics/distributions.rs ----
 // Distribution1D::sample :51-72 over a cdf of n+1 entries
 // `guide` (may be null; wave-uniform): guide_k upper-bound indices for this cdf, see DevSky in rt_types.h
@@ -325,7 +340,7 @@ template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevM
 	const V3 ior = v3(m.ior[0], m.ior[1], m.ior[2]);
 	V3 f0 = vabs((1.0f - ior) / (1.0f + ior));
 	f0 = f0 * f0;
-	const V3 tex = texture_colour<F>(S, m.texture, wi, hit.point);
+	const V3 tex = material_texture_colour<F>(S, m, wi, hit.point);
 	f0 = (1.0f - m.metallic) * f0 + m.metallic * tex; // lerp :89-91
 	return fresnel(dot(wo, h), f0);
 }
@@ -409,11 +424,11 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 1) // lambertian.rs:45-47
-		return texture_colour<F>(S, m.texture, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+		return material_texture_colour<F>(S, m, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
 	if (!F::cmat)
 		return v3s(0.0f);
 	if (m.type == 3 || m.type == 4) // reflect.rs:36-38, refract.rs:51-53
-		return texture_colour<F>(S, m.texture, wo, hit.point);
+		return material_texture_colour<F>(S, m, wo, hit.point);
 	if (m.type == 2) { // trowbridge_reitz.rs:61-74
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
@@ -431,7 +446,7 @@ template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScen
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 1) // lambertian.rs:48-50
-		return texture_colour<F>(S, m.texture, wo, hit.point) * m.param;
+		return material_texture_colour<F>(S, m, wo, hit.point) * m.param;
 	if (!F::cmat)
 		return v3s(0.0f); // unreachable without Reflect/Refract/TrowbridgeReitz
 	if (m.type == 2) { // trowbridge_reitz.rs:75-87
@@ -452,7 +467,7 @@ template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 0) { // emissive.rs:23-26
 		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
-		return m.param * texture_colour<F>(S, m.texture, wo, point);
+		return m.param * material_texture_colour<F>(S, m, wo, point);
 	}
 	return v3s(0.0f);
 }
