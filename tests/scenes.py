@@ -244,3 +244,24 @@ def random_everything(seed, sampler_res=(16, 8)):
     cam = dict(origin=tuple(rng.uniform(-1, 1, 3) * (3, 0.5, 1) + (0, 1.5, 7.0)), lookat=(0.0, 0.8, 0.0), vup=(0.0, 1.0, 0.0),
                fov=float(rng.uniform(35, 75)), aspect_ratio=float(np.float32(16.0) / np.float32(9.0)), aperture=0.0, focus_dist=10.0)
     return sc, cam
+
+
+def floor_under(light=None, sky=None, sampler_res=(0, 0), rho=(0.8, 0.6, 0.4), albedo=0.9):
+    """A Lambertian floor z = 0 (two big triangles, normal +z) under either one emissive sphere
+    `light = (centre_height, radius, colour, strength)` or a Lerp sky `sky = (c1, c2)`: single-bounce scenes
+    whose outgoing radiance at the origin has a closed form (tests/test_oracle_render.py)."""
+    sc = SceneDescription()
+    diffuse = sc.lambertian(sc.solid(rho), albedo)
+    a, b = (-5000.0, -5000.0, 0.0), (5000.0, 5000.0, 0.0)
+    c, d = (-5000.0, 5000.0, 0.0), (5000.0, -5000.0, 0.0)
+    n = (0.0, 0.0, 1.0)
+    sc.triangle([a, b, c], [n, n, n], diffuse)
+    sc.triangle([a, b, d], [n, n, n], diffuse)
+    if light is not None:
+        h, r, colour, strength = light
+        sc.sphere((0.0, 0.0, h), r, sc.emissive(sc.solid(colour), strength))
+    if sky is not None:
+        sc.set_sky(sc.lerp(sky[0], sky[1]), sampler_res)
+    else:
+        sc.set_sky(sc.solid((0.0, 0.0, 0.0)), sampler_res)
+    return sc

@@ -31,6 +31,35 @@ def test_mis_equals_naive(O, sampler_res):
     assert np.linalg.norm(naive - mis) < 4e-3 * max(1.0, np.linalg.norm(naive)), (naive, mis)
 
 
+@pytest.mark.parametrize("method", [abi.RT_METHOD_NAIVE, abi.RT_METHOD_MIS])
+@pytest.mark.parametrize("sampler_res", [(0, 0), (12, 6)])
+def test_sphere_light_over_a_floor_closed_form(O, method, sampler_res):
+    """Irradiance of a Lambertian floor point straight below a spherical source of radiance L, radius R, centre
+    height d is pi L (R/d)^2, so the point's radiance is rho L (R/d)^2 -- one bounce, no interreflection (an
+    emitter ends the path).  Checks cone sampling of the light, its pdf, the MIS weights and the naive estimator
+    against a number neither of them was tuned to."""
+    rho, albedo, colour, strength, d, r = np.array([0.8, 0.6, 0.4]), 0.9, np.array([1.0, 0.7, 0.4]), 6.0, 3.0, 1.0
+    s = O.Scene(scenes.floor_under(light=(d, r, tuple(colour), strength), sampler_res=sampler_res, rho=tuple(rho), albedo=albedo))
+    want = rho * albedo * colour * strength * (r / d) ** 2
+    n = 4_000_000 if method == abi.RT_METHOD_NAIVE else 1_000_000
+    got = s.integrate_ray((2.0, 0.0, 1.5), (-2.0, 0.0, -1.5), method, n, seed=11)
+    assert np.abs(got - want).max() < 4e-3, (got, want)
+
+
+@pytest.mark.parametrize("method,sampler_res", [(abi.RT_METHOD_NAIVE, (0, 0)), (abi.RT_METHOD_MIS, (0, 0)),
+                                                (abi.RT_METHOD_MIS, (50, 25)), (abi.RT_METHOD_MIS, (7, 3))])
+def test_lerp_sky_over_a_floor_closed_form(O, method, sampler_res):
+    """Under the Lerp sky L(w) = c1 t + c2 (1 - t), t = (w.z + 1)/2 (textures/mod.rs:283-291) a floor with normal
+    +z receives E = pi (c1 + c2)/2 + pi (c1 - c2)/3, so its radiance is rho [(c1 + c2)/2 + (c1 - c2)/3]: checks
+    the sky's importance sampling (table build, sample, pdf) and MIS against calculus."""
+    rho, albedo = np.array([0.8, 0.6, 0.4]), 0.9
+    c1, c2 = np.array([0.5, 0.7, 1.0]), np.array([1.0, 0.9, 0.2])
+    s = O.Scene(scenes.floor_under(sky=(tuple(c1), tuple(c2)), sampler_res=sampler_res, rho=tuple(rho), albedo=albedo))
+    want = rho * albedo * ((c1 + c2) / 2 + (c1 - c2) / 3)
+    got = s.integrate_ray((2.0, 0.0, 1.5), (-2.0, 0.0, -1.5), method, 1_500_000, seed=12)
+    assert np.abs(got - want).max() < 2e-3, (got, want)
+
+
 def _f32(x):
     return np.float32(x)
 
