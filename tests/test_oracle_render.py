@@ -60,6 +60,38 @@ def test_lerp_sky_over_a_floor_closed_form(O, method, sampler_res):
     assert np.abs(got - want).max() < 2e-3, (got, want)
 
 
+def test_mirror_floor_shows_the_sky(O):
+    """Reflect with fuzz 0 (materials/reflect.rs:22-43) under the naive integrator: the pixel is tex * Lerp(reflected
+    direction), a deterministic value -- every sample identical, equal to the formula to float rounding."""
+    sc = scenes.SceneDescription()
+    tex = np.array([0.9, 0.8, 0.7])
+    mirror = sc.reflect(sc.solid(tuple(tex)), 0.0)
+    n = (0.0, 0.0, 1.0)
+    a, b, c, d = (-500.0, -500.0, 0.0), (500.0, 500.0, 0.0), (-500.0, 500.0, 0.0), (500.0, -500.0, 0.0)
+    sc.triangle([a, b, c], [n, n, n], mirror)
+    sc.triangle([a, b, d], [n, n, n], mirror)
+    c1, c2 = np.array([0.5, 0.7, 1.0]), np.array([1.0, 0.9, 0.2])
+    sc.set_sky(sc.lerp(tuple(c1), tuple(c2)), (0, 0))
+    s = O.Scene(sc)
+    got = s.integrate_ray((2.0, 0.0, 1.5), (-2.0, 0.0, -1.5), abi.RT_METHOD_NAIVE, 1000, seed=5)
+    t = 0.6 * 0.5 + 0.5  # reflected direction (-0.8, 0, 0.6)
+    want = tex * (c1 * t + c2 * (1 - t))
+    assert np.abs(got - want).max() < 2e-6, (got, want)
+
+
+def test_glass_sphere_in_a_white_sky_is_white(O):
+    """Refract (materials/refract.rs:23-61, white texture) neither absorbs nor emits, so under a uniform sky of
+    radiance 1 every naive path that escapes carries exactly 1: the mean is 1 up to the rare path cut at
+    MAX_DEPTH inside the sphere -- Schlick reflection vs refraction, both branches, conserve energy."""
+    sc = scenes.SceneDescription()
+    sc.sphere((0.0, 0.0, 0.0), 1.0, sc.refract(sc.solid((1.0, 1.0, 1.0)), 1.5))
+    sc.set_sky(sc.solid((1.0, 1.0, 1.0)), (0, 0))
+    s = O.Scene(sc)
+    for origin, direction in (((0.0, 0.0, 4.0), (0.0, 0.0, -1.0)), ((0.7, 0.2, 4.0), (0.0, 0.0, -1.0)), ((0.0, 0.95, 4.0), (0.0, 0.0, -1.0))):
+        got = s.integrate_ray(origin, direction, abi.RT_METHOD_NAIVE, 200_000, seed=6)
+        assert np.abs(got - 1.0).max() < 2e-3, (origin, got)
+
+
 def _f32(x):
     return np.float32(x)
 
