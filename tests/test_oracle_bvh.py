@@ -140,3 +140,70 @@ def test_check_hit_index_visibility(O):
     assert h["found"][0] == 1 and abs(h["t"][0] - 4.0) < 1e-5 and h["out"][0] == 1
     assert h["found"][1] == 0  # origin inside the ground sphere: its wall is crossed before the light
     assert h["found"][2] == 0  # misses the light entirely
+
+
+def test_triangle_hits_match_moeller_trumbore_in_f64(O):
+    """The watertight triangle test (primitives/triangle.rs:105-216: shear, edge functions, f64 fallback,
+    conservative t bound) against an independent Moeller-Trumbore in numpy float64 over every triangle: same
+    closest triangle, same t, hit point on the triangle's plane, barycentric uv as triangle.rs:179 defines it."""
+    rng = np.random.default_rng(21)
+    n_tri, n_rays = 300, 20000
+    sc = scenes.random_triangle_mesh(n_tri, seed=5, extent=3.0, edge=1.5, emissive_every=0, sampler_res=(0, 0))
+    s = O.Scene(sc)
+    rng_scene = np.random.default_rng(5)  # the generator of scenes.random_triangle_mesh, replayed
+    centres = rng_scene.uniform(-3.0, 3.0, (n_tri, 3)).astype(np.float32)
+    e1 = rng_scene.uniform(-1.5, 1.5, (n_tri, 3)).astype(np.float32)
+    e2 = rng_scene.uniform(-1.5, 1.5, (n_tri, 3)).astype(np.float32)
+    v0 = centres.astype(np.float64)
+    v1 = (centres + e1).astype(np.float64)
+    v2 = (centres + e2).astype(np.float64)
+    org = rng.uniform(-6, 6, (n_rays, 3)).astype(np.float32)
+    dirs = (rng.uniform(-2, 2, (n_rays, 3)).astype(np.float32) - org)
+    h = s.check_hit(org, dirs)
+    o = org.astype(np.float64)
+    d = dirs.astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    E1, E2 = v1 - v0, v2 - v0
+    best_t = np.full(n_rays, np.inf)
+    best_k = np.full(n_rays, -1)
+    best_uv = np.zeros((n_rays, 2))
+    for k in range(n_tri):
+        p = np.cross(d, E2[k])
+        det = p @ E1[k]
+        ok = np.abs(det) > 1e-14
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = o - v0[k]
+        u = np.einsum("ij,ij->i", tv, p) * inv
+        q = np.cross(tv, E1[k])
+        v = np.einsum("ij,ij->i", d, q) * inv
+        t = (q @ E2[k]) * inv
+        hit = ok & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 1e-9) & (t < best_t)
+        best_t = np.where(hit, t, best_t)
+        best_k = np.where(hit, k, best_k)
+        best_uv[hit] = np.stack([u[hit], v[hit]], axis=1)
+    got_hit = h["index"] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    want_hit = best_k >= 0
+    assert want_hit.mean() > 0.2
+    # P-hazard 4 (SURVEY 8a): Ray::new / Axis::swap_z swap x<->z for Y-dominant rays too, so such rays are sheared
+    # along x instead of their dominant axis; when |d.x| is small the conservative `t < delta_t` bound
+    # (triangle.rs:160-177) blows up and the reference REJECTS genuine hits.  The oracle reproduces that: every
+    # disagreement is a Y-dominant ray with a small x component, and it is always a miss where f64 sees a hit.
+    ad = np.abs(d)
+    y_dominant = (ad[:, 1] > ad[:, 2]) & ~((ad[:, 0] > ad[:, 1]) & (ad[:, 0] > ad[:, 2]))
+    assert (got_hit == want_hit)[~y_dominant].mean() > 0.9995  # rays through an edge may flip between f32 and f64
+    lost = want_hit & ~got_hit & y_dominant
+    assert not (got_hit & ~want_hit & y_dominant).any()
+    assert 0 < lost.sum() < 0.03 * (want_hit & y_dominant).sum() and ad[lost, 0].max() < 0.1
+    both = got_hit & want_hit
+    slot_to_original = s.primitive_order()
+    same = slot_to_original[h["index"][both].astype(np.int64)] == best_k[both]
+    assert same[~y_dominant[both]].mean() > 0.9995
+    # a Y-dominant ray that lost its nearest triangle reports a farther one, never a nearer one
+    assert (h["t"][both][~same] > best_t[both][~same] - 1e-4).all()
+    sel = np.nonzero(both)[0][same]
+    assert np.allclose(h["t"][sel], best_t[sel], rtol=2e-5, atol=2e-5)
+    # uv = b1 (1,0) + b2 (1,1) with b1, b2 the weights of v1, v2 (triangle.rs:179)
+    b1, b2 = best_uv[sel, 0], best_uv[sel, 1]
+    assert np.allclose(h["uv"][sel, 0], b1 + b2, atol=2e-4) and np.allclose(h["uv"][sel, 1], b2, atol=2e-4)
+    point = o[sel] + d[sel] * best_t[sel, None]
+    assert np.abs(h["point"][sel] - point).max() < 1e-4
