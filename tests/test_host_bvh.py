@@ -66,3 +66,55 @@ def test_host_only_scene_cannot_render(hb):
     with pytest.raises(hb.RtHipError) as e:
         g.check_hit(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32))
     assert e.value.code == abi.RT_ERR_NO_DEVICE
+
+
+def test_malformed_descriptors_are_refused_not_crashed(hb):
+    """rt_scene_create validates what it is handed (indices into textures / materials / meshes / triangle data,
+    primitive and material types, sky) and returns RT_ERR_INVALID_ARGUMENT; NaN or infinite geometry is data,
+    not an error (the reference would build a tree from it too).  None of it may crash."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    n_refused = n_accepted = 0
+    for trial in range(300):
+        sc, _ = scenes.random_everything(int(rng.integers(0, 40)))
+        desc = sc.desc()
+        kind = int(rng.integers(0, 10))
+        prims = C.cast(desc.primitives, C.POINTER(C.c_uint32))  # 10 dwords per rt_primitive_desc
+        k = int(rng.integers(0, desc.n_primitives))
+        if kind == 0:
+            prims[10 * k + 0] = int(rng.integers(3, 1000))                  # primitive type
+        elif kind == 1:
+            prims[10 * k + 1] = desc.n_materials + int(rng.integers(0, 5))  # material index
+        elif kind == 2:
+            desc.materials[int(rng.integers(0, desc.n_materials))].texture = desc.n_textures + 3
+        elif kind == 3:
+            desc.materials[int(rng.integers(0, desc.n_materials))].type = int(rng.integers(5, 100))
+        elif kind == 4:
+            desc.textures[int(rng.integers(0, desc.n_textures))].type = int(rng.integers(5, 100))
+        elif kind == 5:
+            desc.sky.material = desc.n_materials
+        elif kind == 6:
+            desc.sky.sampler_res_x, desc.sky.sampler_res_y = 0, 7           # Distribution2D::new would panic
+        elif kind == 7:
+            desc.split_type = int(rng.integers(3, 50))
+        elif kind == 9:  # a mesh / triangle-data index past the end of its array (falls back to a bad type if none exists)
+            hit = [i for i in range(desc.n_primitives) if prims[10 * i] in (abi.RT_PRIM_MESH_TRIANGLE, abi.RT_PRIM_TRIANGLE)]
+            if hit:
+                i = hit[int(rng.integers(0, len(hit)))]
+                if prims[10 * i] == abi.RT_PRIM_MESH_TRIANGLE:
+                    prims[10 * i + 3 + int(rng.integers(0, 6))] = 0x7FFFFFF0   # point / normal index
+                else:
+                    prims[10 * i + 2], prims[10 * i + 3] = 0xFFFFFFF0, 0        # triangle-data index (u64)
+            else:
+                prims[10 * k + 0] = 77
+        else:  # NaN / inf in the geometry words of one primitive: accepted, builds, must not hang or crash
+            prims[10 * k + 2 + int(rng.integers(0, 4))] = int(rng.choice([0x7FC00000, 0x7F800000, 0xFF800000]))
+        h = C.c_void_p()
+        rc = hb.lib().rt_scene_create(C.byref(desc), C.c_int(abi.RT_DEVICE_NONE), C.byref(h))
+        if rc == 0:
+            n_accepted += 1
+            hb.lib().rt_scene_destroy(h)
+        else:
+            assert rc == abi.RT_ERR_INVALID_ARGUMENT, (kind, rc, hb.lib().rt_last_error())
+            n_refused += 1
+    assert n_refused > 150 and n_accepted > 10
