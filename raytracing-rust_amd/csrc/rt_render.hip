@@ -73,6 +73,10 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #define RT_FULL_WAVES 3 // waves per SIMD of the full-feature variants under the coarse schedule (a few dozen spilled
                         // registers, still faster than 2: all_materials naive 131 -> 109 ms, MIS 292 -> 275 ms); fine keeps 2
 #endif
+#ifndef RT_FULL_FINE_WAVES
+#define RT_FULL_FINE_WAVES 4 // full-feature variants under the fine schedule (200 k triangles + glass and GGX spheres:
+                             // 2 waves 130 / 61 ms MIS / naive, 3 waves 114 / 48, 4 waves 114 / 42)
+#endif
 #ifndef RT_SIMPLE_FINE_WAVES
 #define RT_SIMPLE_FINE_WAVES 4 // simple variants under the fine schedule: 128 VGPRs (about 40 spilled) against 168 at 3 waves:
                                // 100 k triangles naive 28.9 -> 25.2 ms, MIS 50.9 -> 48.8; 1 M: 37.7 -> 35.6, 62.6 -> 61.2
@@ -116,11 +120,11 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 // SIMD, but three 256-thread workgroups with a 41 KB sky table each are all the LDS of a CU holds, so
 // they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1); so do the simple
 // variants under the coarse schedule.  Fine-schedule kernels keep 256 threads (their LDS goes to the
-// traversal stacks) at 4 waves per SIMD, full-feature kernels 3 (coarse) or 2 (fine).
+// traversal stacks) at 4 waves per SIMD, full-feature coarse kernels 3.
 template <class F, bool FINE = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
-	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? 2 : RT_FULL_WAVES)
+	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? RT_FULL_FINE_WAVES : RT_FULL_WAVES)
 	                                      : (spheres_only ? RT_SPHERES_WAVES : (FINE ? RT_SIMPLE_FINE_WAVES : RT_SIMPLE_COARSE_WAVES));
 	static constexpr int block = spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256);
 };
