@@ -26,7 +26,7 @@ class Counters(C.Structure):
 
 
 def build(force=False):
-    if os.environ.get("ORACLE_LIB"):  # an alternative build of the same sources, e.g. with -fsanitize=address,undefined
+    if os.environ.get("ORACLE_LIB"):  # an alternative build of the same sources (tests/sanitize/run.sh builds one with the address and UB sanitizers)
         return os.environ["ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     if force or not os.path.exists(so):
