@@ -150,6 +150,24 @@ def resolve_path(path, base_dir):
     return os.path.join(base_dir, path)
 
 
+def decode_image_rgb32f(path):
+    """What `image::open(path).to_rgb32f()` yields for 8-bit images (textures/mod.rs:212-246): RGB, each channel
+    `value as f32 / 255.0`, no gamma.  Decoding is host-side I/O outside the hot path; it uses Pillow when it is
+    installed and refuses other bit depths rather than guess their scaling."""
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise SsmlError("image textures need Pillow to decode; pass decoded pixels through SceneDescription.image") from e
+    import numpy as np
+    with Image.open(path) as im:
+        if im.mode not in ("RGB", "RGBA", "L", "LA", "P", "1"):
+            raise SsmlError(f"image texture {path}: unsupported pixel format {im.mode} (8-bit images only)")
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    if rgb.shape[0] == 0 or rgb.shape[1] == 0:
+        raise SsmlError(f"image texture {path} is empty")
+    return rgb.astype(np.float32) / np.float32(255.0)
+
+
 def parse_obj(text):
     """Wavefront OBJ as the `wavefront_obj` 10.0 crate presents it to loader/src/obj.rs:11-61: a list of
     objects, each with its OWN vertex / normal arrays (indices made object-relative) and its faces grouped
@@ -263,8 +281,11 @@ def load_str(src, split_type=abi.RT_SPLIT_SAH, perlin_seed=0, base_dir=None):
         elif ttype == "perlin":
             ran_vecs, perm = perlin_tables(perlin_seed)
             idx = sc.perlin(ran_vecs, perm)
-        elif ttype == "image":
-            raise SsmlError("image textures need a decoder; pass decoded pixels through SceneDescription.image")
+        elif ttype == "image":  # ImageTexture::load + ::new  loader/src/textures.rs:51-60, textures/mod.rs:208-246
+            filename = p.text("filename")
+            if filename is None:
+                raise SsmlError("missing required filename")
+            idx = sc.image(decode_image_rgb32f(resolve_path(filename, base_dir)))
         else:
             raise SsmlError(f"required a known value for texture type, found '{ttype}'")
         if name is not None:

@@ -171,3 +171,45 @@ def test_obj_without_normals_is_rejected(tmp_path):
     with pytest.raises(ssml.SsmlError) as e:
         ssml.load_file(str(tmp_path / "a.ssml"))
     assert "vertex normals" in str(e.value)
+
+
+def test_image_texture_is_decoded_like_to_rgb32f(pkg, hb, tmp_path):
+    """`texture … ( type image filename … )` (loader/src/textures.rs:51-60): 8-bit pixels become value / 255 in f32,
+    RGB order, no gamma -- what image::open(..).to_rgb32f() yields (textures/mod.rs:236-246)"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(4)
+    px = rng.integers(0, 256, (5, 9, 3), dtype=np.uint8)
+    Image.fromarray(px, "RGB").save(tmp_path / "tex.png")
+    src = """
+camera (
+    origin 0 0 3
+    lookat 0 0 0
+    vup 0 1 0
+    fov 40
+)
+texture pic (
+    type image
+    filename tex.png
+)
+material m (
+    type lambertian
+    texture pic
+    albedo 0.8
+)
+primitive (
+    type sphere
+    material m
+    centre 0 0 0
+    radius 1
+)
+sky (
+    texture pic
+)
+"""
+    ls = pkg.ssml.load_str(src, base_dir=str(tmp_path))
+    t = [t for t in ls.scene.textures if t.type == abi.RT_TEX_IMAGE][0]
+    assert (t.image_width, t.image_height) == (9, 5)
+    got = np.ctypeslib.as_array(t.image_rgb, shape=(5, 9, 3))
+    assert np.array_equal(got, px.astype(np.float32) / np.float32(255.0))
+    with pytest.raises(pkg.ssml.SsmlError):
+        pkg.ssml.load_str("texture t (\n    type image\n)\nsky (\n    texture t\n)\n")
