@@ -266,3 +266,21 @@ def save_image(filename, image, gamma=2.2):
     a = np.ascontiguousarray(image, dtype=np.float32)
     h, w, _ = a.shape
     _check(lib().rt_output_save(filename.encode(), _p(a, C.c_float), C.c_uint32(w), C.c_uint32(h), C.c_float(gamma)))
+
+
+def get_readable_duration(seconds):
+    """output::get_readable_duration (crates/output/src/lib.rs:33-63), whole seconds as Duration::as_secs."""
+    total = int(seconds)
+    days, hours, minutes, secs = total // 86400, (total % 86400) // 3600, (total % 3600) // 60, total % 60
+
+    def part(n, unit):
+        return "" if n == 0 else (f"{n} {unit}, " if n == 1 else f"{n} {unit}s, ")
+
+    tail = "~0 seconds" if secs == 0 else (f"{secs} second" if secs == 1 else f"{secs} seconds")
+    return part(days, "day") + part(hours, "hour") + part(minutes, "minute") + tail
+
+
+def final_statistics(seconds, ray_count, samples):
+    """The message of output::print_final_statistics (crates/output/src/lib.rs:115-124)."""
+    return (f"Finished rendering:\n\tSamples:\t{samples}\n\tTime taken:\t{get_readable_duration(seconds)}\n"
+            f"\tRays shot:\t{ray_count} @ {ray_count / seconds / 1000000.0:.2f} Mray/s")

@@ -111,3 +111,13 @@ def test_filename_rules(hb, tmp_path):
         with pytest.raises(hb.RtHipError) as e:
             hb.save_image(bad, img)  # like the reference: exactly one '.', dispatch on the extension
         assert e.value.code == code
+
+
+def test_final_statistics_text(hb):
+    """output::get_readable_duration / print_final_statistics (crates/output/src/lib.rs:33-63,115-124)"""
+    d = hb.get_readable_duration
+    assert d(0.4) == "~0 seconds" and d(1) == "1 second" and d(59.9) == "59 seconds"
+    assert d(60) == "1 minute, ~0 seconds" and d(3600 + 2 * 60 + 1) == "1 hour, 2 minutes, 1 second"
+    assert d(2 * 86400 + 3 * 3600 + 7) == "2 days, 3 hours, 7 seconds"
+    text = hb.final_statistics(2.0, 3_000_000, 1024)
+    assert text == "Finished rendering:\n\tSamples:\t1024\n\tTime taken:\t2 seconds\n\tRays shot:\t3000000 @ 1.50 Mray/s"
