@@ -6,8 +6,9 @@ import scenes
 ls = scenes.load_ssml("rtweekend1"); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
 base = None
 for shards in (1, 2, 4, 8):
-    for S in (1, 2, 4, 8, 16):
+    for S in (1, 4, 16, 32, 64):
         if shards == 1 and S > 4: continue
+        if shards == 2 and S > 16: continue
         worst = 0.0
         for idx in sorted({0, shards - 1}):
             o = abi.default_render_opts(1920, 1080, 1024); o.sample_split = S; o.shard_index, o.shard_count = idx, shards

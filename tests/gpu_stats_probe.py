@@ -5,7 +5,8 @@ pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_modu
 import scenes
 for name in ("rtweekend1", "overshadowed"):
     ls = scenes.load_ssml(name); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
-    o = abi.default_render_opts(1920, 1080, 64)
+    o = abi.default_render_opts(1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 64)
+    o.sample_split = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     out = (C.c_ulonglong * 64)()
     hb.lib().rt_debug_stats(out, 1)
     img, rays = g.render(cam, o)
@@ -15,6 +16,6 @@ for name in ("rtweekend1", "overshadowed"):
     tot = max(1, sum(sect))
     names = ["vote+claim", "P:gen", "P:walk", "P:shade", "Q:light", "Q:shadow walk", "Q:scatter", "Q:walk", "Q:shade"]
     print("   wave wall-clock share: " + "  ".join(f"{nm} {100*v/tot:.1f}%" for nm, v in zip(names, sect)))
-    n = 1920 * 1080 * 64
+    n = 1920 * 1080 * int(o.samples_per_pixel)
     print(f"{name}: TRACE iters {ti} avg active {ta/ti:.1f}/64 (gen lanes/iter {gen/ti:.1f}) | LIGHT iters {li} avg active {la/li:.1f}/64 | "
           f"per sample: trace-lane-steps {ta/n:.2f} light-lane-steps {la/n:.2f}; wave-iters per 64 samples: trace {ti*64/n:.2f} light {li*64/n:.2f}")
