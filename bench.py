@@ -123,7 +123,7 @@ def main():
     # Sharded over N GPUs each owns 1/N of them, so the passes of a pixel are split into S chunks
     # (rt_render_opts.sample_split: same samples, chunk means combined in fixed order, image moves by
     # ~1e-7) with S the power of two that keeps >= 32 work items per lane (measured on one GPU's share of
-    # an 8-way sharded frame: 58 ms at S = 1, 19 ms at S = 32, ideal 18 ms).  N = 1 keeps S = 1.
+    # an 8-way sharded frame: 42.9 ms at S = 1, 17.5 ms at S = 64, ideal 15.4 ms).  N = 1 keeps S = 1.
     lanes = 262144
     split = 1
     while world > 1 and (WIDTH * HEIGHT // world) * split < 32 * lanes and split < SPP // 16:
