@@ -65,6 +65,10 @@ constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
 #define RT_DRAIN_LANES 6
 #endif
 constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase runs once this many lanes wait for it
+#ifndef RT_DRAIN_LANES_HEAVY
+#define RT_DRAIN_LANES_HEAVY RT_DRAIN_LANES
+#endif
+constexpr uint32_t kDrainLanesHeavy = RT_DRAIN_LANES_HEAVY; // ... the same for the long phases (GEN, SHADE, LIGHT, SCATTER)
 #ifndef RT_NODE_STEPS_PER_VOTE
 #define RT_NODE_STEPS_PER_VOTE 16
 #endif
@@ -612,6 +616,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 #ifdef RT_STATS
 	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
 	unsigned long long st_sect[9] = {}, st_mark = wall_clock64();
+	unsigned long long st_fine_clock[PH_COUNT + 1] = {};
 	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
@@ -679,7 +684,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			uint32_t best_n = 0;
 #pragma unroll
 			for (int k = PH_COUNT - 1; k >= 0; --k) {
-				if (k != PH_NODE && run < 0 && cnt[k] >= kDrainLanes) {
+				if (k != PH_NODE && run < 0 && cnt[k] >= (k == PH_LEAF ? kDrainLanes : kDrainLanesHeavy)) {
 					run = k;
 					best_n = cnt[k];
 				}
@@ -708,6 +713,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 				st_fine_active[run] += best_n;
 			}
 #endif
+#ifdef RT_STATS
+			if (lane == 0u) { // wall-clock share per fine phase: slot 6 = vote + work acquisition, 0..5 = the phase run last
+				const unsigned long long now_ = wall_clock64();
+				st_fine_clock[6] += now_ - st_mark;
+				st_mark = now_;
+			}
+#endif
 			if (run == PH_NODE) {
 				// a few node steps per vote: a walk is tens to hundreds of them and the vote is not free
 #pragma unroll 1
@@ -730,6 +742,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 				if (ph == PH_SCATTER)
 					do_scatter(PL, ray);
 			}
+#ifdef RT_STATS
+			if (lane == 0u) {
+				const unsigned long long now_ = wall_clock64();
+				st_fine_clock[run] += now_ - st_mark;
+				st_mark = now_;
+			}
+#endif
 		} else {
 			// ---- tiny trees (a walk is a handful of steps): two super-phases.
 			//   TRACE = GEN + closest walk + SHADE     LIGHT = LIGHT + shadow walk + SCATTER
@@ -815,6 +834,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	if (lane == 0u) {
 		for (int k = 0; k < 9; ++k)
 			atomicAdd(&g_stats[40 + k], st_sect[k]);
+		for (int k = 0; k <= PH_COUNT; ++k)
+			atomicAdd(&g_stats[50 + k], st_fine_clock[k]);
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
 		atomicAdd(&g_stats[2], st_iters[1]); atomicAdd(&g_stats[3], st_active[1]);
 		atomicAdd(&g_stats[4], st_gen);

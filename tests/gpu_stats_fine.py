@@ -18,3 +18,6 @@ for method in (0, 1):
     n = 1920 * 1080 * 8
     print(f"   lane node steps {out[20]} ({out[20]/n:.1f}/sample)  primitive tests {out[21]} ({out[21]/n:.2f}/sample)  max stack {out[22]}")
     print(f"   dead node visits {out[23]/max(1,out[20]):.3f} of all; with a pruned hit child {out[24]/max(1,out[20]):.3f}; all hit children pruned {out[25]/max(1,out[20]):.3f}")
+    clk = [out[50 + k] for k in range(7)]
+    tot_c = max(1, sum(clk))
+    print("   wave wall-clock share: " + "  ".join(f"{nm} {100*v/tot_c:.1f}%" for nm, v in zip(["GEN", "NODE", "LEAF", "SHADE", "LIGHT", "SCATTER", "vote+claim"], clk)))
