@@ -54,7 +54,7 @@ def load_workload(pkg, name):
     return ls.scene, ls.camera_params
 
 
-def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=12.0):
+def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=24.0):
     """Time the CPU oracle on a bounded sample: same scene, resolution, seed and method, fewer spp."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O  # the ONLY use of oracle/ in this file: the reported CPU baseline
