@@ -1,92 +1,262 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the HIP path tracer on BASELINE.json's headline configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One "step" = one complete render of scenes/rtweekend1.ssml at 1920x1080, 1024 spp, MIS, max_depth 50
-(BASELINE.json configs[1]) = 2.123 G samples, scene already resident in HBM.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the image's 8x8 tiles are interleaved over the ranks, every
-rank renders its tiles, and one RCCL gather per step assembles the frame on rank 0 (strong scaling:
-total work is fixed).  Rank 0 prints ONE JSON line.
+One "step" = one complete render of the workload's frame, scene already resident in HBM.  The default
+workload is BASELINE.json configs[1]: scenes/rtweekend1.ssml at 1920x1080, 1024 spp, MIS, max_depth 50 =
+2.123 G samples per step.  Other workloads: `overshadowed` = configs[2], `mesh1m` =
+configs[3] on one GPU, `mesh10m` = one rank's 1/8 shard of configs[4] (the only scene that exceeds the
+Infinity Cache), `cfg1` = configs[0] (CPU oracle only, no GPU).
 
-`roofline` prices the render kernel against HBM bandwidth with the ALGORITHMIC bytes of SURVEY 8(d)
-(counted by the oracle under the reference's traversal semantics: profiles/algorithmic_bytes.json,
-DESIGN.md section 5) and the kernel's own duration measured with HIP events on its launch stream.
-`cpu_baseline` times the CPU oracle (oracle/, a restatement of the reference's algorithm -- the Rust
-binary cannot be built in this pipeline) on this box's host cores on a bounded sample of the same
-workload.  The oracle is used for nothing else here.
+Multi-GPU (--gpus N > 1): one process per GPU.  Launched bare (`python bench.py --gpus N`), this process
+is only a launcher: it starts N rank children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+environment) BEFORE anything here touches the GPU, waits for them and exits non-zero if any of them
+failed.  Launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already
+exist and each process is one of them.  The image's 8x8 tiles are interleaved over the ranks
+(samplers/random_sampler.rs:45-52 partitions by pixel chunk the same way: no cross-chunk dependency), every
+rank renders its tiles, ONE RCCL gather per step assembles the frame on rank 0 (strong scaling: the frame is
+fixed).  Rank 0 prints ONE JSON line.
+
+`roofline` names the bound that actually limits the dominant kernel:
+  * rtweekend1 / overshadowed: the scene lives in SGPRs / LDS, HBM sees 12 bytes per pixel per frame, so the
+    bound is VALU issue: VALU wave-instructions per sample (PMC, profiles/kernel_counters.json, measured on
+    the kernel build named there) x samples / kernel time against CUs x 4 SIMDs x clock / 2.
+  * mesh1m: dependent random 64-byte node fetches: L1->L2 requests per second against the measured
+    random-fetch ceiling of the memory system (profiles/r01d_random_fetch_microbench.txt).
+  * mesh10m: HBM: bytes the pruned walk requests per sample (counted live by the -DRT_STATS diagnostic
+    build on an untimed pass) x samples / kernel time against 8 TB/s, with the fabric bytes the PMC
+    counters saw as `traffic`.
+SURVEY 8(d)'s algorithmic bytes (reference traversal semantics, counted by the oracle) stay as a secondary
+field; they are requested bytes, not HBM bytes, and never a roofline fraction.
+`cpu_baseline` times the CPU oracle (oracle/, a restatement of the reference's algorithm -- the Rust binary
+cannot be built in this pipeline) on this box's host cores on a bounded sample of the same workload.  The
+oracle is used for nothing else here.
 """
 import argparse
-import ctypes as C
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT = 1920, 1080
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# The default workload is BASELINE.json configs[1]; --workload selects configs[2] / configs[3] for the numbers
-# quoted in DESIGN.md.  bytes = SURVEY 8(d) algorithmic bytes per sample, counted by
-# tests/count_algorithmic_bytes.py (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest hit,
-# 64 B/sky op, 12 B/pixel) -> profiles/algorithmic_bytes.json
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6 290 GB/s measured achievable
+HBM_ACHIEVABLE_GBS = 6290.0
+CLOCK_HZ = 2.4e9               # max engine clock (MI355X_MICROARCH.md chip-level parameters)
+SIMDS = 256 * 4
+VALU_ISSUE_PEAK = SIMDS * CLOCK_HZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32
+# dependent random record fetches, every lane its own chain (tests/microbench/random_fetch.hip ->
+# profiles/r01d_random_fetch_microbench.txt): 115 G/s when the set is L2-resident, 57 G/s beyond L2
+L2_FETCH_CEILING_RESIDENT = 115.0e9
+L2_FETCH_CEILING_BEYOND = 57.0e9
+
+# bytes: SURVEY 8(d) algorithmic bytes per sample under REFERENCE traversal semantics, counted by
+# tests/probes/count_algorithmic_bytes.py (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest
+# hit, 64 B/sky op, 12 B/pixel) -> profiles/algorithmic_bytes.json
 WORKLOADS = {
-    "rtweekend1": {"spp": 1024, "seed": 1, "bytes": 446.77, "feat": "rt::Feat<false, false, false, false>", "variant": "1, false, false, true"},
-    "overshadowed": {"spp": 1024, "seed": 1, "bytes": 488.42, "feat": "rt::Feat<true, true, false, false>", "variant": "1, false, false, true"},
-    # walk_bytes: what the pruned GPU walk itself requests per sample, from the -DRT_STATS diagnostic build
-    # (tests/gpu_stats_fine.py: 330.0 node steps x 64 B + 5.95 primitive tests x 48 B + 0.67 hits x 48 B normals)
-    "mesh1m": {"spp": 256, "seed": 42, "bytes": 38990.98, "feat": "rt::Feat<true, true, false, false>", "variant": "1, true, true, false",
-               "walk_bytes": 330.0 * 64 + 5.95 * 48 + 0.67 * 48},
+    "rtweekend1": {"width": 1920, "height": 1080, "spp": 1024, "seed": 1, "bytes": 446.77, "bound": "valu_issue",
+                   "label": "scenes/rtweekend1.ssml", "config": "BASELINE configs[1]"},
+    "overshadowed": {"width": 1920, "height": 1080, "spp": 1024, "seed": 1, "bytes": 488.42, "bound": "valu_issue",
+                     "label": "scenes/overshadowed.ssml", "config": "BASELINE configs[2]"},
+    "mesh1m": {"width": 1920, "height": 1080, "spp": 256, "seed": 42, "bytes": 38990.98, "bound": "l2_request_rate",
+               "label": "synthetic 1M random-triangle mesh", "config": "BASELINE configs[3] on one GPU",
+               "triangles": 1000000, "extent": 10.0},
+    # configs[4] is 4096 spp on 8 GPUs; one GPU's share of it is every 8th tile.  The cost of a sample does not
+    # depend on how many follow it, so the timed frame carries 64 of the 4096 passes (about 7 s per step).
+    "mesh10m": {"width": 4096, "height": 4096, "spp": 64, "full_spp": 4096, "seed": 42, "bytes": None, "bound": "hbm",
+                "label": "synthetic 10M random-triangle mesh", "config": "one rank's 1/8 tile shard of BASELINE configs[4]",
+                "triangles": 10000000, "extent": 20.0, "shard": (0, 8), "aspect": 1.0},
 }
-SCENE, SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE = "rtweekend1", 1024, 1, 446.77
+
+
+def source_hash():
+    """sha256 over the kernel sources: ties PMC-derived counters to the build they were measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raytracing-rust_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rt_detmath.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_workload(pkg, name):
     """(scene description, camera parameters) of a workload"""
-    if name == "mesh1m":  # BASELINE configs[3]: the synthetic 1 M random-triangle mesh (generator: tests/scenes.py)
+    w = WORKLOADS[name]
+    if "triangles" in w:  # the synthetic random-triangle meshes (generator: tests/scenes.py)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import scenes
-        return scenes.random_triangle_mesh(1000000, seed=42), dict(scenes.MESH_CAMERA)
+        cam = dict(scenes.MESH_CAMERA)
+        if "aspect" in w:
+            cam["aspect_ratio"] = w["aspect"]
+        return scenes.random_triangle_mesh(w["triangles"], seed=w["seed"], extent=w["extent"]), cam
     ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", name + ".ssml"))
     return ls.scene, ls.camera_params
 
 
-def cpu_baseline(pkg, scene_desc, camera_params, target_seconds=24.0):
-    """Time the CPU oracle on a bounded sample: same scene, resolution, seed and method, fewer spp."""
+def workload_opts(abi, name, spp=None):
+    w = WORKLOADS[name]
+    o = abi.default_render_opts(w["width"], w["height"], spp or w["spp"], method=abi.RT_METHOD_MIS, seed=w["seed"])
+    if "shard" in w:
+        o.shard_index, o.shard_count = w["shard"]
+    return o
+
+
+def cpu_baseline(pkg, name, scene_desc, camera_params, target_seconds=20.0):
+    """Time the CPU oracle on a bounded sample: same scene, resolution, seed, method and shard, fewer spp."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O  # the ONLY use of oracle/ in this file: the reported CPU baseline
     abi = pkg.abi
+    w = WORKLOADS[name]
     cores = os.cpu_count() or 1
     s = O.Scene(scene_desc)
     cam = O.camera_new(**camera_params)
-    # calibration, untimed: a strip of the frame at 2 spp (the big mesh needs seconds per full pass on the CPU)
-    strip = abi.default_render_opts(WIDTH, HEIGHT, 2, seed=SEED)
-    strip.shard_index, strip.shard_count = 0, 16  # every 16th tile, interleaved over the whole frame
+    base = workload_opts(abi, name, 1)
+    owned = (w["width"] * w["height"]) // base.shard_count
+    # calibration, untimed: every 16th tile of the shard at 2 spp (big meshes need seconds per full pass on the CPU)
+    strip = workload_opts(abi, name, 2)
+    strip.shard_index, strip.shard_count = base.shard_index, base.shard_count * 16
     t0 = time.time()
     s.render(cam, strip, n_threads=cores)
     per_spp = max((time.time() - t0) * 16.0 / 2.0, 1e-3)
-    spp = int(max(1, min(512, SPP, target_seconds / per_spp)))
+    spp = int(max(1, min(512, w["spp"], target_seconds / per_spp)))
     t0 = time.time()
-    s.render(cam, abi.default_render_opts(WIDTH, HEIGHT, spp, seed=SEED), n_threads=cores)
+    s.render(cam, workload_opts(abi, name, spp), n_threads=cores)
     dt = time.time() - t0
-    return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{SCENE} {WIDTH}x{HEIGHT}, {spp} of {SPP} spp, MIS, max_depth 50, {dt:.1f} s of CPU work"}
+    return {"value": owned * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{name} {w['width']}x{w['height']}" + (f" shard {base.shard_index}/{base.shard_count}" if base.shard_count > 1 else "") +
+                      f", {spp} of {w.get('full_spp', w['spp'])} spp, MIS, max_depth 50, {dt:.1f} s of CPU work"}
+
+
+def run_cfg1(args):
+    """BASELINE configs[0]: rtweekend1 at 400x225x64 on the CPU path (the oracle; no GPU), with max_depth 8 as
+    BASELINE says and 50 as the reference has it (integrators/mod.rs:7) -- both reported."""
+    pkg = importlib.import_module("raytracing-rust_amd")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    abi = pkg.abi
+    ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", "rtweekend1.ssml"))
+    s = O.Scene(ls.scene)
+    cam = O.camera_new(**ls.camera_params)
+    cores = os.cpu_count() or 1
+    W, H, SPP = 400, 225, 64
+    chunks = (W * H + 9999) // 10000  # random_sampler.rs:31-32,45: par_chunks_mut(10 000 px): at most 9 busy threads
+    res = {}
+    for depth in (8, 50):
+        o = abi.default_render_opts(W, H, SPP, method=abi.RT_METHOD_MIS, seed=1)
+        o.max_depth = depth
+        for _ in range(args.warmup):
+            s.render(cam, o, n_threads=cores)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, rays = s.render(cam, o, n_threads=cores)
+        dt = (time.perf_counter() - t0) / args.steps
+        res[depth] = {"Msamples_per_s": W * H * SPP / dt / 1e6, "ms_per_step": dt * 1e3, "rays_shot": int(rays)}
+    out = {"metric": "Msamples/s on rtweekend1.ssml 400x225x64spp (CPU oracle)", "value": res[8]["Msamples_per_s"], "unit": "Msamples/s",
+           "n_gpus": 0, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res[8]["ms_per_step"], "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "scenes/rtweekend1.ssml 400x225 64spp MIS seed=1 on the CPU oracle (BASELINE configs[0]); value = max_depth 8",
+                      "threads": cores, "chunks_per_pass": chunks,
+                      "note": "per-pass barrier over 10 000-pixel chunks as the reference: 9 chunks, so at most 9 threads are busy",
+                      "max_depth_8": res[8], "max_depth_50": res[50]},
+           "cpu_baseline": {"value": res[50]["Msamples_per_s"], "unit": "Msamples/s", "cores": min(cores, chunks), "kind": "port",
+                            "sample": "the whole of configs[0] at the reference's max_depth 50"}}
+    print(json.dumps(out), flush=True)
+
+
+def walk_stats_child(name):
+    """Runs in a child process with RT_HIP_LIB = the -DRT_STATS diagnostic build: one untimed pass of the
+    workload's frame at 2 spp; prints what the pruned walk did per sample."""
+    import ctypes as C
+    pkg = importlib.import_module("raytracing-rust_amd")
+    hb = importlib.import_module("raytracing-rust_amd.hip_backend")
+    scene_desc, camera_params = load_workload(pkg, name)
+    g = hb.HipScene(scene_desc, device=0)
+    cam = hb.camera_new(**camera_params)
+    o = workload_opts(pkg.abi, name, 2)
+    o.output_layout = pkg.abi.RT_LAYOUT_SHARD
+    out = (C.c_ulonglong * 64)()
+    hb.lib().rt_debug_stats(out, 1)
+    g.render(cam, o)
+    hb.lib().rt_debug_stats(out, 1)
+    n = (o.width * o.height // o.shard_count) * 2
+    print(json.dumps({"node_steps_per_sample": out[20] / n, "primitive_tests_per_sample": out[21] / n, "max_stack": int(out[22]),
+                      "counted_on": f"{o.width}x{o.height} shard {o.shard_index}/{o.shard_count} x 2 spp"}), flush=True)
+
+
+def walk_stats(name):
+    lib = os.path.join(ROOT, "raytracing-rust_amd", "librt_hip_stats.so")
+    if not os.path.exists(lib):
+        return None
+    env = dict(os.environ, RT_HIP_LIB=lib)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--walk-stats-child", name], env=env, capture_output=True,
+                           text=True, timeout=900)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N rank processes from here.  This
+    process imports neither torch nor the HIP library and never touches a GPU; it waits for the ranks and
+    exits non-zero if any of them failed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and deadline is None:
+                deadline = time.time() + 30.0  # one rank died: the others will hang in a collective; give them 30 s
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    for p in procs:
+        rc = rc or p.returncode
+    sys.exit(1 if rc else 0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="rtweekend1")
+    ap.add_argument("--no-walk-stats", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["cfg1"], default="rtweekend1")
+    ap.add_argument("--walk-stats-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
-    global SCENE, SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE
-    SCENE = args.workload
-    SPP, SEED, ALGORITHMIC_BYTES_PER_SAMPLE = WORKLOADS[SCENE]["spp"], WORKLOADS[SCENE]["seed"], WORKLOADS[SCENE]["bytes"]
+    if args.walk_stats_child:
+        return walk_stats_child(args.walk_stats_child)
+    name = args.workload
+    if name == "cfg1":
+        args.steps = args.steps or 3
+        args.warmup = 1 if args.warmup is None else args.warmup
+        return run_cfg1(args)
+    w = WORKLOADS[name]
+    # default: a timed region of 10 s or more (80 x 125 ms for the headline workload), so that coarse telemetry sees the GPU busy
+    if args.steps is None:
+        args.steps = {"rtweekend1": 80, "overshadowed": 50, "mesh1m": 6, "mesh10m": 2}[name]
+    if args.warmup is None:
+        args.warmup = 3 if w["bound"] == "valu_issue" else 1
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)  # never returns
 
     import torch
     import torch.distributed as dist
@@ -94,9 +264,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks: launch with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 ...")
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if "shard" in w and world > 1:
+        raise SystemExit(f"workload {name} is one rank's shard by definition: run it with --gpus 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP back end has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -110,14 +281,15 @@ def main():
     hb = importlib.import_module("raytracing-rust_amd.hip_backend")
     D = importlib.import_module("raytracing-rust_amd.distributed")
     abi = pkg.abi
+    WIDTH, HEIGHT, SPP = w["width"], w["height"], w["spp"]
 
-    scene_desc, camera_params = load_workload(pkg, SCENE)
+    scene_desc, camera_params = load_workload(pkg, name)
     t0 = time.time()
     scene = hb.HipScene(scene_desc, device=local_rank)  # BVH build + upload: not part of the timed region
     build_s = time.time() - t0
     cam = hb.camera_new(**camera_params)
 
-    opts = abi.default_render_opts(WIDTH, HEIGHT, SPP, method=abi.RT_METHOD_MIS, seed=SEED)
+    opts = workload_opts(abi, name)
     # A lane folds a whole pixel by default (the reference's sequential running mean), so a GPU cannot
     # use more lanes than it owns pixels.  One GPU owns 2.07 M pixels for 262 144 resident lanes: fine.
     # Sharded over N GPUs each owns 1/N of them, so the passes of a pixel are split into S chunks
@@ -129,16 +301,21 @@ def main():
     while world > 1 and (WIDTH * HEIGHT // world) * split < 32 * lanes and split < SPP // 16:
         split *= 2
     opts.sample_split = split
-    sopts = D.shard_opts(opts, rank, world)
-    gather = D.ShardGather(opts, rank, world, device)
-    shard = gather.new_shard_buffer()
-    frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=device) if rank == 0 else None
+    if "shard" in w:  # one rank's shard of a larger job: render it packed, nothing to gather
+        shard_index, shard_count = w["shard"]
+    else:
+        shard_index, shard_count = rank, world
+    sopts = D.shard_opts(opts, shard_index, shard_count)
+    gather = D.ShardGather(opts, rank, world, device) if "shard" not in w else None
+    n_shard_floats = hb.output_floats(sopts)
+    shard = torch.zeros(n_shard_floats // 3, 3, dtype=torch.float32, device=device) if gather is None else gather.new_shard_buffer()
+    frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=device) if (rank == 0 and gather is not None) else None
     d_rays = torch.zeros(1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream(device)
 
     def step():
         scene.render_device(cam, sopts, shard.data_ptr(), d_rays.data_ptr(), stream.cuda_stream)
-        return gather.gather(shard, frame)
+        return gather.gather(shard, frame) if gather is not None else shard
 
     def barrier():
         if use_dist:
@@ -162,20 +339,72 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     rays = D.reduce_rays(d_rays.clone(), world)
+    launch = scene.last_launch_info()
 
     if rank == 0:
-        samples_per_step = WIDTH * HEIGHT * SPP
+        samples_per_step = (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else 1)) * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
         k_ms = sum(kernel_ms) / len(kernel_ms)
         # the dominant (only) kernel: one render launch per step on this rank, covering 1/world of the samples
         launch_samples = samples_per_step / world
-        achieved = ALGORITHMIC_BYTES_PER_SAMPLE * launch_samples / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp) and world == 1:
-            traffic = json.load(open(tp)).get(f"{SCENE}_{WIDTH}x{HEIGHT}x{SPP}_mis", {}).get("hbm_bytes_per_launch")
+        k_s = k_ms * 1e-3
+        # PMC-derived per-sample counters of this kernel variant, with the hash of the sources they were measured on
+        counters = {}
+        cp = os.path.join(ROOT, "profiles", "kernel_counters.json")
+        if os.path.exists(cp):
+            counters = json.load(open(cp)).get(name, {})
+        current = bool(counters) and counters.get("source_hash") == source_hash() and counters.get("kernel") == launch["kernel"]
+        roof = {"bound": w["bound"], "kernel": launch["kernel"], "kernel_ms": k_ms,
+                "launch": {k: launch[k] for k in ("block_threads", "n_blocks", "blocks_per_cu", "waves_per_simd", "lds_bytes", "n_cus",
+                                                  "sky_in_lds", "scene_in_lds")},
+                "traffic": counters.get("hbm_bytes_per_launch") if world == 1 else None,
+                "counters_source": counters.get("source"), "counters_measured_on_this_build": current}
+        if w["bound"] == "valu_issue":
+            vps = counters.get("valu_wave_instructions_per_sample")
+            achieved = vps * launch_samples / k_s if vps else None
+            roof.update({"achieved": achieved / 1e9 if achieved else None, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G VALU wave-instructions/s",
+                         "frac": min(achieved / VALU_ISSUE_PEAK, 1.0) if achieved else None,
+                         "valu_wave_instructions_per_sample": vps, "lane_utilisation": counters.get("valu_lane_utilisation"),
+                         "note": "scene and sky tables live in SGPRs/LDS; HBM sees 12 B/pixel per frame (traffic), so the bound is VALU "
+                                 "issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"})
+        elif w["bound"] == "l2_request_rate":
+            rps = counters.get("l2_read_requests_per_sample")
+            hit = counters.get("l2_hit_rate")
+            achieved = rps * launch_samples / k_s if rps else None
+            ceiling = None
+            if hit is not None:  # harmonic blend of the two measured ceilings at the kernel's own L2 hit rate
+                ceiling = 1.0 / (hit / L2_FETCH_CEILING_RESIDENT + (1.0 - hit) / L2_FETCH_CEILING_BEYOND)
+            roof.update({"achieved": achieved / 1e9 if achieved else None, "peak": L2_FETCH_CEILING_RESIDENT / 1e9, "unit": "G L1->L2 read requests/s",
+                         "frac": min(achieved / L2_FETCH_CEILING_RESIDENT, 1.0) if achieved else None,
+                         "l2_read_requests_per_sample": rps, "l2_hit_rate": hit,
+                         "blended_ceiling_at_this_hit_rate": ceiling / 1e9 if ceiling else None,
+                         "frac_of_blended_ceiling": min(achieved / ceiling, 1.0) if (achieved and ceiling) else None,
+                         "lane_utilisation": counters.get("valu_lane_utilisation"),
+                         "note": "every node step is a dependent, effectively random 64-byte fetch; peak = measured dependent-random-fetch "
+                                 "rate of an L2-resident set (115 G/s), 57 G/s beyond L2 (profiles/r01d_random_fetch_microbench.txt)"})
+        ws = None
+        if "triangles" in w and world == 1 and not args.no_walk_stats:
+            ws = walk_stats(name)
+        if ws:
+            wb = ws["node_steps_per_sample"] * 64 + ws["primitive_tests_per_sample"] * 48
+            roof["pruned_walk"] = dict(ws, bytes_per_sample=wb, requested_GBps=wb * launch_samples / k_s / 1e9,
+                                       note="counted by the -DRT_STATS build on an untimed pass: 64 B per node step + 48 B per primitive test")
+        if w["bound"] == "hbm":
+            wb = roof.get("pruned_walk", {}).get("bytes_per_sample")
+            achieved = wb * launch_samples / k_s / 1e9 if wb else None
+            measured = counters.get("hbm_bytes_per_launch") / counters.get("kernel_ms_when_measured") / 1e6 if counters.get("hbm_bytes_per_launch") else None
+            roof.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": min(achieved / HBM_PEAK_GBS, 1.0) if achieved else None,
+                         "achievable_peak": HBM_ACHIEVABLE_GBS,
+                         "fabric_GBps_from_pmc": measured, "l2_hit_rate": counters.get("l2_hit_rate"),
+                         "lane_utilisation": counters.get("valu_lane_utilisation"),
+                         "note": "achieved = bytes the pruned walk REQUESTS (64 B/node step + 48 B/primitive test, counted live) / kernel time; "
+                                 "L1/L2 absorb part of it: fabric_GBps_from_pmc is what left L2 (Infinity Cache + HBM) in the committed profile"})
+        if w["bytes"]:
+            roof["survey_8d_algorithmic"] = {"bytes_per_sample": w["bytes"], "requested_GBps": w["bytes"] * launch_samples / k_s / 1e9,
+                                             "note": "requested bytes under REFERENCE traversal semantics (no pruning, oracle-counted); not HBM bytes, not a roofline fraction"}
         out = {
-            "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp" if SCENE == "rtweekend1" else f"Msamples/s on {SCENE} {WIDTH}x{HEIGHT}x{SPP}spp",
+            "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp" if name == "rtweekend1" else f"Msamples/s on {name} {WIDTH}x{HEIGHT}x{SPP}spp",
             "value": value,
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -187,29 +416,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"scenes/{SCENE}.ssml" if SCENE != "mesh1m" else "synthetic 1M random-triangle mesh (BASELINE configs[3])") +
-                                   f" {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={SEED}",
-                       "parallelism": f"tile-sharded x{world}, replicated BVH, one RCCL gather per frame" if world > 1 else "1 GPU",
+            "config": {"workload": f"{w['label']} {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={w['seed']} ({w['config']})",
+                       "parallelism": (f"{world} ranks (one per GPU), 8x8 tiles interleaved t % {world}, replicated BVH, one RCCL gather per frame"
+                                       if world > 1 else ("1 GPU" + (f", shard {w['shard'][0]} of {w['shard'][1]}" if "shard" in w else ""))),
                        "sample_split": split,
                        "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
                        "scene_build_s": build_s},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"rt::render_kernel<{WORKLOADS[SCENE]['variant']}, {WORKLOADS[SCENE]['feat']}>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_sample": ALGORITHMIC_BYTES_PER_SAMPLE,
-                         "note": ("algorithmic (requested) bytes under reference traversal semantics; the scene and "
-                                  "its 41 KB sky table live in LDS/L1/L2, so real HBM traffic is ~12 B/pixel (see traffic) and "
-                                  "this kernel is VALU/latency-bound, not HBM-bound, by design") if SCENE != "mesh1m" else
-                                 ("algorithmic (requested) bytes under reference traversal semantics (no pruning); the pruned walk "
-                                  "requests 2.8x fewer and is bound by the random 64-byte fetch rate of L2/Infinity Cache "
-                                  "(DESIGN.md section 5)")},
+            "roofline": roof,
         }
-        if "walk_bytes" in WORKLOADS[SCENE]:
-            wb = WORKLOADS[SCENE]["walk_bytes"]
-            out["roofline"]["pruned_walk_bytes_per_sample"] = wb
-            out["roofline"]["pruned_walk_requested_GBps"] = wb * launch_samples / (k_ms * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, scene_desc, camera_params)
+            out["cpu_baseline"] = cpu_baseline(pkg, name, scene_desc, camera_params)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -314,6 +314,30 @@ int rt_sample_image(rt_scene *scene, const rt_camera *camera, const rt_render_op
  * (synchronises that stream).  The kernel's launch count is returned through n_launches. */
 int rt_last_kernel_ms(rt_scene *scene, float *ms, uint32_t *n_launches);
 
+/* What the most recent rt_render / rt_render_device on this scene actually launched: the kernel
+ * instantiation rt_render_device selected (its automatic choices depend on the scene, the method and
+ * the occupancy query), its launch geometry and its LDS.  For measurement tools (bench.py prints it);
+ * `kernel` is the demangled instantiation name as rocprofv3 reports it.  Does not synchronise. */
+typedef struct rt_launch_info {
+	int32_t method;         /* rt_render_method */
+	int32_t pruned;         /* 1: t-pruned walk, 0: exhaustive (the reference's amount of work) */
+	int32_t fine;           /* 1: every phase voted (big trees), 0: two super-phases */
+	int32_t sky_in_lds;     /* sky CDF + guide tables staged in LDS */
+	int32_t scene_in_lds;   /* whole scene staged in LDS (tiny scenes) */
+	int32_t feature_set;    /* 0 spheres-only, 1 simple, 2 full */
+	uint32_t block_threads; /* workgroup size */
+	uint32_t n_blocks;      /* persistent grid */
+	uint32_t blocks_per_cu; /* resident workgroups per CU (occupancy query) */
+	uint32_t waves_per_simd;/* blocks_per_cu * block_threads / 256 */
+	uint32_t lds_bytes;     /* dynamic LDS per workgroup */
+	uint32_t n_cus;
+	uint32_t sample_split;
+	uint32_t reserved;
+	uint64_t n_items;       /* work items of the launch (pixels x sample_split, incl. edge-tile padding) */
+	char kernel[160];
+} rt_launch_info;
+int rt_last_launch_info(const rt_scene *scene, rt_launch_info *out);
+
 /* ---- output stage, the step right after the path: crates/output/src/lib.rs:74-113 save_data_to_image.
  * Host-side (no GPU needed).  rt_output_rgb8 is the reference's pixel conversion
  * `(val.powf(1.0 / gamma) * 255.999) as u8` (`as u8` saturates, NaN -> 0); rt_output_save dispatches on

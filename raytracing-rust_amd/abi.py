@@ -179,6 +179,27 @@ class SamplerProgressC(C.Structure):  # rt_sampler_progress
     ]
 
 
+class LaunchInfo(C.Structure):  # rt_launch_info
+    _fields_ = [
+        ("method", C.c_int32),
+        ("pruned", C.c_int32),
+        ("fine", C.c_int32),
+        ("sky_in_lds", C.c_int32),
+        ("scene_in_lds", C.c_int32),
+        ("feature_set", C.c_int32),
+        ("block_threads", C.c_uint32),
+        ("n_blocks", C.c_uint32),
+        ("blocks_per_cu", C.c_uint32),
+        ("waves_per_simd", C.c_uint32),
+        ("lds_bytes", C.c_uint32),
+        ("n_cus", C.c_uint32),
+        ("sample_split", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("n_items", C.c_uint64),
+        ("kernel", C.c_char * 160),
+    ]
+
+
 # rt_presentation_update: int (*)(void *data, const rt_sampler_progress *, uint64_t samples_done)
 PresentationUpdate = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SamplerProgressC), C.c_uint64)
 
@@ -196,6 +217,7 @@ EXPECTED_SIZES = {
     "rt_ray_desc": (RayDesc, 24),
     "rt_bvh_node": (BvhNode, 56),
     "rt_sampler_progress": (SamplerProgressC, 32),
+    "rt_launch_info": (LaunchInfo, 224),
 }
 
 # every symbol include/rt_hip.h declares
@@ -219,6 +241,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_output_floats",
     "rt_shard_pixel_order",
     "rt_last_kernel_ms",
+    "rt_last_launch_info",
     "rt_output_rgb8",
     "rt_output_save",
     "rt_check_hit",

@@ -53,7 +53,7 @@ static int hip_fail(hipError_t e, const char *what)
 			return hip_fail(e_, #expr);     \
 	} while (0)
 
-// Measured crossovers (tests/gpu_crossover_probe.py, tests/gpu_crossover_mesh.py, 1080p):
+// Measured crossovers (tests/probes/gpu_crossover_probe.py, tests/probes/gpu_crossover_mesh.py, 1080p):
 //   exhaustive walk + coarse schedule wins up to ~100 primitives, the pruned walk beyond;
 //   the fine schedule (every step voted) wins from a few thousand triangles (10 k: 36 -> 26 ms, 1 M: 189 -> 77 ms)
 //   but only ties on sphere-only scenes even at 16 k (96 vs 106 ms): sphere leaves are cheap, triangle leaves
@@ -90,6 +90,7 @@ struct rt_scene {
 	hipStream_t copy_stream = nullptr;
 	hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	size_t max_lds = 65536;
+	rt_launch_info last_launch{};
 };
 
 template <class T> static int upload(rt_scene *s, const T *src, size_t count, const T **dst)
@@ -569,7 +570,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 
 	// traversal: exhaustive (the reference's own amount of work) for tiny trees where pruning cannot
 	// pay, t-pruned otherwise; both select the same winner (rt_intersect.h)
-	// and how finely the wave votes: measured crossovers on random sphere scenes (tests/gpu_crossover_probe.py)
+	// and how finely the wave votes: measured crossovers on random sphere scenes (tests/probes/gpu_crossover_probe.py)
 	bool prune = s->traversal_mode == -1 ? s->dev.n_prims > kPruneAbove : s->traversal_mode == 1;
 	const bool fine = s->schedule_mode == -1 ? (prune && s->dev.n_prims > (s->dev.has_triangles ? kFineAboveTriangles : kFineAboveSpheres))
 	                                         : s->schedule_mode == 1;
@@ -627,6 +628,29 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	std::memcpy(cam.horizontal, camera->horizontal, 12);
 	std::memcpy(cam.vertical, camera->vertical, 12);
 
+	{ // what is about to run, for rt_last_launch_info
+		rt_launch_info &L = s->last_launch;
+		std::memset(&L, 0, sizeof L);
+		L.method = o->render_method;
+		L.pruned = prune ? 1 : 0;
+		L.fine = fine ? 1 : 0;
+		L.sky_in_lds = sky_lds ? 1 : 0;
+		L.scene_in_lds = scene_lds ? 1 : 0;
+		L.feature_set = s->feature_set;
+		L.block_threads = render_block_threads(s->feature_set, fine);
+		L.n_blocks = (uint32_t)n_blocks;
+		L.blocks_per_cu = (uint32_t)blocks_per_cu;
+		L.waves_per_simd = (uint32_t)blocks_per_cu * L.block_threads / 256u;
+		L.lds_bytes = (uint32_t)lds_bytes;
+		L.n_cus = (uint32_t)s->n_cus;
+		L.sample_split = split;
+		L.n_items = P.n_items;
+		static const char *const feat_names[3] = {"rt::Feat<false, false, false, false>", "rt::Feat<true, true, false, false>",
+		                                          "rt::Feat<true, true, true, true>"};
+		// pick_render (rt_render.hip) folds these: naive never stages the sky, fine implies pruned
+		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s>", (int)o->render_method, prune ? "true" : "false",
+		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set]);
+	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
 	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
@@ -760,6 +784,16 @@ int rt_last_kernel_ms(rt_scene *s, float *ms, uint32_t *n_launches)
 	HIP_TRY(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
 	if (n_launches)
 		*n_launches = s->n_launches;
+	return RT_OK;
+}
+
+int rt_last_launch_info(const rt_scene *s, rt_launch_info *out)
+{
+	if (!s || !out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (!s->timed)
+		return fail(RT_ERR_INVALID_ARGUMENT, "no render has been launched on this scene");
+	*out = s->last_launch;
 	return RT_OK;
 }
 

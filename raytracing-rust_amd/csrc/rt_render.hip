@@ -140,7 +140,7 @@ template <class F, bool FINE = false> struct KernelShape {
 #define RT_SECTION(k) do { } while (0)
 #endif
 #ifdef RT_STATS
-// diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/gpu_stats_probe.py
+// diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/probes/gpu_stats_probe.py
 __device__ unsigned long long g_stats[64];
 #endif
 

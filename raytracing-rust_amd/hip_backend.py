@@ -161,6 +161,14 @@ class HipScene:
         _check(lib().rt_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_launch_info(self):
+        """What the most recent render launched (rt_launch_info) as a dict."""
+        li = abi.LaunchInfo()
+        _check(lib().rt_last_launch_info(self._h, C.byref(li)))
+        d = {name: getattr(li, name) for name, _ in abi.LaunchInfo._fields_ if name not in ("kernel", "reserved")}
+        d["kernel"] = li.kernel.decode()
+        return d
+
     # ---- AccelerationStructure::check_hit / check_hit_index for batches ----
     def check_hit(self, origins, directions):
         rays = _pack_rays(origins, directions)

@@ -1,12 +1,12 @@
 """Counts, with the oracle under REFERENCE traversal semantics, the work per sample of the bench
 workloads and prints the algorithmic bytes per sample of SURVEY section 8(d):
     bytes(sample) = 32*N_node + 36*N_tri + 16*N_sph + 52*N_hits + 64*N_sky_ops + 12/spp
-Run:  python tests/count_algorithmic_bytes.py   (writes profiles/algorithmic_bytes.json)"""
+Run:  python tests/probes/count_algorithmic_bytes.py   (writes profiles/algorithmic_bytes.json)"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import oracle as O  # noqa: E402

@@ -1,6 +1,6 @@
-"""Renders the synthetic random-triangle mesh a few times (for rocprof): python tests/gpu_mesh_bench.py n W H spp method reps"""
+"""Renders the synthetic random-triangle mesh a few times (for rocprof): python tests/probes/gpu_mesh_bench.py n W H spp method reps"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import scenes

@@ -1,8 +1,8 @@
 """Large synthetic mesh probe (BASELINE configs 3/4 shape) on the GPU box:
-python tests/gpu_mesh_probe.py <n_triangles> <W> <H> <spp> [extent]"""
+python tests/probes/gpu_mesh_probe.py <n_triangles> <W> <H> <spp> [extent]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import oracle as O, scenes

@@ -1,7 +1,7 @@
-"""Quick perf + parity probe on the GPU box: python tests/gpu_perf_probe.py [spp]"""
+"""Quick perf + parity probe on the GPU box: python tests/probes/gpu_perf_probe.py [spp]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import oracle as O, scenes

@@ -1,7 +1,7 @@
-"""Ad-hoc GPU-vs-oracle probe (run on the GPU box): python tests/gpu_probe.py [scene] [W H SPP]"""
+"""Ad-hoc GPU-vs-oracle probe (run on the GPU box): python tests/probes/gpu_probe.py [scene] [W H SPP]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 pkg = importlib.import_module("raytracing-rust_amd")
 hb = importlib.import_module("raytracing-rust_amd.hip_backend")

@@ -1,7 +1,7 @@
 """Progressive rendering cost: rt_sample_image (double-buffered, copy stream) vs a loop of blocking rt_render calls.
-python tests/gpu_progressive_probe.py [W H spp]"""
+python tests/probes/gpu_progressive_probe.py [W H spp]"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import numpy as np

@@ -1,6 +1,6 @@
-"""Renders one of the .ssml scenes a few times (for rocprof): python tests/gpu_scene_bench.py scene W H spp method reps"""
+"""Renders one of the .ssml scenes a few times (for rocprof): python tests/probes/gpu_scene_bench.py scene W H spp method reps"""
 import importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import scenes

@@ -1,8 +1,8 @@
 """Pure traversal throughput: rt_check_hit on primary camera rays of the synthetic mesh.
-python tests/gpu_trace_bench.py n_tris W H [shuffle]"""
+python tests/probes/gpu_trace_bench.py n_tris W H [shuffle]"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend")
 import scenes

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC + stats for an arbitrary command: tests/run_rocprof_cmd.sh <tag> <python-script-and-args...>
+# PMC + stats for an arbitrary command: tests/probes/run_rocprof_cmd.sh <tag> <python-script-and-args...>
 set -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 cd /tmp
 for V in "" "shuffle"; do
   OUT=$R/gpurun_out/prof_trace_$V; mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tests/gpu_trace_bench.py ${1:-1000000} 1920 1080 $V > $OUT/out.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tests/probes/gpu_trace_bench.py ${1:-1000000} 1920 1080 $V > $OUT/out.txt 2>&1
   grep traversal $OUT/out.txt
   grep check_hit $OUT/*/*kernel_stats.csv | sed 's/.*)",//'
 done
