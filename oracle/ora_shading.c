@@ -316,6 +316,57 @@ static float tr_g1(float alpha, vec3 normal, vec3 h, vec3 v)
 	const float tmp = alpha_sq + (1.0f - alpha_sq) * cos_sq;
 	return 2.0f * c / (sqrtf(tmp) + c);
 }
+/* test hooks: d / g1 / g2 exactly as the shading code above calls them, over arrays, so that tests/ can restate the
+ * reference's quadrature identities (statistics/bxdfs/trowbridge_reitz.rs:128-230) on THESE functions */
+int ora_tr_d_many(float alpha, const float *cos_theta, uint64_t n, float *out)
+{
+	for (uint64_t i = 0; i < n; ++i)
+		out[i] = tr_d(alpha, cos_theta[i]);
+	return RT_OK;
+}
+int ora_tr_g1_many(float alpha, const float normal[3], const float *h, const float v[3], uint64_t n, float *out)
+{
+	for (uint64_t i = 0; i < n; ++i)
+		out[i] = tr_g1(alpha, v3_from(normal), v3_from(&h[3 * i]), v3_from(v));
+	return RT_OK;
+}
+int ora_tr_g2_many(float alpha, const float normal[3], const float *h, const float incoming[3], const float *outgoing, uint64_t n,
+                   float *out)
+{
+	for (uint64_t i = 0; i < n; ++i)
+		out[i] = tr_g2(alpha, v3_from(normal), v3_from(&h[3 * i]), v3_from(incoming), v3_from(&outgoing[3 * i]));
+	return RT_OK;
+}
+/* test hook: Distribution2D::new + n draws of Distribution2D::sample (distributions.rs:83-104), and the discrete pdf
+ * y_distribution.pdf[y] * x_distributions[y].pdf[x] the reference's random_2d tests compare against (:206-213) */
+int ora_dist2d_sample_many(const float *values, uint64_t n_values, uint64_t width, uint64_t seed, uint64_t n, uint32_t *out_x,
+                           uint32_t *out_y, float *out_pdf)
+{
+	if (!values || width == 0 || n_values == 0 || n_values % width != 0)
+		return RT_ERR_INVALID_ARGUMENT;
+	ora_dist2d d;
+	dist2d_new(&d, values, n_values, width);
+	ora_ctx ctx;
+	ora_ctx_init(&ctx);
+	rt_rng_seed(&ctx.rng, seed, 0, 0);
+	for (uint64_t i = 0; i < n; ++i) {
+		const uint64_t sv = ora_dist1d_sample(&d.y_distribution, &ctx); /* Distribution2D::sample :100-104 */
+		const uint64_t su = ora_dist1d_sample(&d.x_distributions[sv], &ctx);
+		out_x[i] = (uint32_t)su;
+		out_y[i] = (uint32_t)sv;
+	}
+	if (out_pdf)
+		for (uint64_t y = 0; y < d.dim_y; ++y)
+			for (uint64_t x = 0; x < d.dim_x; ++x)
+				out_pdf[y * d.dim_x + x] = d.y_distribution.pdf[y] * d.x_distributions[y].pdf[x];
+	ora_ctx_free(&ctx);
+	for (uint64_t r = 0; r < d.dim_y; ++r)
+		dist1d_free(&d.x_distributions[r]);
+	free(d.x_distributions);
+	dist1d_free(&d.y_distribution);
+	return RT_OK;
+}
+
 /* trowbridge_reitz_vndf.rs:9-15  isotropic::vndf */
 static float tr_vndf(float a, vec3 h, vec3 incoming)
 {

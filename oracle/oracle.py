@@ -237,6 +237,40 @@ def dist1d(values, n, seed=1):
     return idx, pdf, cdf
 
 
+def dist2d(values, width, n, seed=1):
+    """Distribution2D::new(values, width) + n draws of .sample(); returns (x, y, discrete pdf [height, width])"""
+    values = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+    x = np.zeros(n, dtype=np.uint32)
+    y = np.zeros(n, dtype=np.uint32)
+    pdf = np.zeros(values.size, dtype=np.float32)
+    _check(lib().ora_dist2d_sample_many(_p(values, C.c_float), C.c_uint64(values.size), C.c_uint64(width), C.c_uint64(seed),
+                                        C.c_uint64(n), _p(x, C.c_uint32), _p(y, C.c_uint32), _p(pdf, C.c_float)))
+    return x, y, pdf.reshape(-1, width)
+
+
+def tr_d(alpha, cos_theta):
+    c = np.ascontiguousarray(cos_theta, dtype=np.float32).reshape(-1)
+    out = np.zeros(c.size, dtype=np.float32)
+    _check(lib().ora_tr_d_many(C.c_float(alpha), _p(c, C.c_float), C.c_uint64(c.size), _p(out, C.c_float)))
+    return out
+
+
+def tr_g1(alpha, normal, h, v):
+    h = np.ascontiguousarray(h, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(h.shape[0], dtype=np.float32)
+    _check(lib().ora_tr_g1_many(C.c_float(alpha), _f3(normal), _p(h, C.c_float), _f3(v), C.c_uint64(h.shape[0]), _p(out, C.c_float)))
+    return out
+
+
+def tr_g2(alpha, normal, h, incoming, outgoing):
+    h = np.ascontiguousarray(h, dtype=np.float32).reshape(-1, 3)
+    o = np.ascontiguousarray(outgoing, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(h.shape[0], dtype=np.float32)
+    _check(lib().ora_tr_g2_many(C.c_float(alpha), _f3(normal), _p(h, C.c_float), _f3(incoming), _p(o, C.c_float),
+                                C.c_uint64(h.shape[0]), _p(out, C.c_float)))
+    return out
+
+
 def sort_by_indices(values, indices):
     v = np.ascontiguousarray(values, dtype=np.uint64).copy()
     i = np.ascontiguousarray(indices, dtype=np.uint64)

@@ -75,6 +75,14 @@ int ora_eval_pdfs(const ora_scene *scene, int32_t which, const float incoming[3]
 int ora_dist1d_sample_many(const float *values, uint64_t n_values, uint64_t seed, uint64_t n, uint64_t *out_index,
                            float *out_pdf /* n_values */, float *out_cdf /* n_values+1 */);
 /* utility::sort_by_indices (utility/mod.rs:119-134) on an array of u64 */
+/* GGX terms over arrays and Distribution2D sampling: hooks for the restated reference tests
+ * (statistics/bxdfs/trowbridge_reitz.rs:128-230, statistics/distributions.rs:206-300) */
+int ora_tr_d_many(float alpha, const float *cos_theta, uint64_t n, float *out);
+int ora_tr_g1_many(float alpha, const float normal[3], const float *h, const float v[3], uint64_t n, float *out);
+int ora_tr_g2_many(float alpha, const float normal[3], const float *h, const float incoming[3], const float *outgoing, uint64_t n,
+                   float *out);
+int ora_dist2d_sample_many(const float *values, uint64_t n_values, uint64_t width, uint64_t seed, uint64_t n, uint32_t *out_x,
+                           uint32_t *out_y, float *out_pdf);
 int ora_sort_by_indices(uint64_t *values, uint64_t n, const uint64_t *indices);
 /* sky tables as built by Sky::new: cdf rows (res_y x (res_x+1)) then marginal cdf (res_y+1) */
 int ora_sky_tables(const ora_scene *scene, float *row_cdf, float *marginal_cdf);

@@ -133,3 +133,122 @@ def test_distribution_1d_sampling(O, shape):  # distributions.rs:186-300 (1-D ca
     idx, pdf, cdf = O.dist1d(vals, 400000, seed=19)
     counts = np.bincount(idx, minlength=vals.size)
     assert chi2_ok(counts, pdf.astype(np.float64) / pdf.sum(), 400000) > 1e-3
+
+
+# ---- Distribution2D: statistics/distributions.rs:206-300 (random_2d_small / _medium / _large) ----
+# The reference fills an x-by-y table with uniform values in [0, 100), builds Distribution2D::new(values, x), draws
+# 100 000 samples per batch (64 batches averaged, 10 repeats, Sidak-corrected p >= 0.01) and chi-squares the histogram
+# of (x, y) cells against y_distribution.pdf[y] * x_distributions[y].pdf[x].  Restated on the oracle's Distribution2D
+# with one large draw per case (the 64-batch average is a variance reduction of the same histogram).
+@pytest.mark.parametrize("x_res,y_res,n", [(3, 3, 400000),        # random_2d_small   :287-290
+                                            (30, 60, 2000000),     # random_2d_medium  :292-295
+                                            (800, 1200, 12000000)])  # random_2d_large   :297-300
+def test_distribution_2d_sampling(O, x_res, y_res, n):
+    rng = np.random.default_rng(x_res * 7919 + y_res)
+    values = rng.uniform(0.0, 100.0, x_res * y_res).astype(np.float32)
+    x, y, pdf = O.dist2d(values, x_res, n, seed=23)
+    assert x.max() < x_res and y.max() < y_res  # the reference's `unreachable!()` arm (:226-231)
+    assert abs(float(pdf.astype(np.float64).sum()) - 1.0) < 1e-3
+    # the discrete pdf is the normalised table (Distribution1D::new of rows and of row sums, :12-44, :83-99)
+    table = values.astype(np.float64).reshape(y_res, x_res)
+    assert np.abs(pdf.astype(np.float64) - table / table.sum()).max() < 2e-6 / (x_res * y_res) ** 0.5 + 1e-9
+    counts = np.bincount(y.astype(np.int64) * x_res + x, minlength=x_res * y_res)
+    p = chi2_ok(counts, pdf.astype(np.float64).reshape(-1) / pdf.astype(np.float64).sum(), n)
+    assert p > 1e-3, p
+
+
+# ---- GGX identities: statistics/bxdfs/trowbridge_reitz.rs:128-230 ----
+# The reference integrates with nested adaptive Simpson over an 80 x 160 (theta, phi) grid (integrate_over_sphere,
+# spherical_sampling.rs:39-62) and draws alpha and the directions from thread_rng; here the integrands are built from
+# the ORACLE's d / g1 / g2 (f32, the functions the shading code calls) at fixed alphas and directions and integrated in
+# float64 with Gauss-Legendre in cos(theta) x uniform phi.  Tolerance 1e-4, the reference's own (measured residuals:
+# 1e-8 .. 8e-5, the largest on the weak furnace).
+TR_TOL = 1e-4
+_GL_X, _GL_W = np.polynomial.legendre.leggauss(600)
+_PHI = (np.arange(1200) + 0.5) / 1200 * 2 * np.pi
+
+
+def sphere_quadrature():
+    cz, ph = np.meshgrid(_GL_X, _PHI, indexing="ij")
+    s = np.sqrt(np.maximum(0.0, 1.0 - cz ** 2))
+    dirs = np.stack([s * np.cos(ph), s * np.sin(ph), cz], axis=-1).reshape(-1, 3)
+    w = np.repeat(_GL_W, len(_PHI)) * (2 * np.pi / len(_PHI))
+    return dirs, w
+
+
+def unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.linalg.norm(v)
+
+
+def wi_from(cos_theta, phi):  # -generate_wi (spherical_sampling.rs:237-242): a direction in the upper hemisphere
+    s = np.sqrt(1 - cos_theta ** 2)
+    return np.array([s * np.cos(phi), s * np.sin(phi), cos_theta])
+
+
+Z = np.array([0.0, 0.0, 1.0])
+TR_CASES = [(0.15, 0.35, 1.0), (0.4, 0.8, 4.0), (0.8, 0.6, 2.5)]  # (alpha, cos theta of the fixed direction, its phi)
+
+
+@pytest.mark.parametrize("alpha,cos_theta,phi", TR_CASES)
+def test_tr_g1_cos(O, alpha, cos_theta, phi):  # g1_cos_test :128-143: int g1(h, wi) max(wi.h, 0) d(h.z) dh = cos theta_i
+    incoming = wi_from(cos_theta, phi)
+    h, w = sphere_quadrature()
+    f = O.tr_g1(alpha, Z, h, incoming).astype(np.float64) * np.maximum(h @ incoming, 0.0) * O.tr_d(alpha, h[:, 2]).astype(np.float64)
+    assert abs((f * w).sum() - cos_theta) < TR_TOL
+
+
+@pytest.mark.parametrize("alpha", [0.15, 0.4, 0.8])
+def test_tr_projected_area_local(O, alpha):  # projected_area_test_local :145-152: int d(h.z) h.z dh = 1
+    h, w = sphere_quadrature()
+    f = O.tr_d(alpha, h[:, 2]).astype(np.float64) * h[:, 2]
+    assert abs((f * w).sum() - 1.0) < TR_TOL
+
+
+@pytest.mark.parametrize("alpha", [0.15, 0.4, 0.8])
+def test_tr_projected_area_non_local(O, alpha):  # projected_area_test_non_local :154-162
+    normal = unit([0.3, -0.5, 0.81])
+    h, w = sphere_quadrature()
+    c = h @ normal
+    f = O.tr_d(alpha, c).astype(np.float64) * c
+    assert abs((f * w).sum() - 1.0) < TR_TOL
+
+
+def _h_upper(a, b, normal):  # (a + b).normalised(), flipped to the normal's side (:170-173, :193-196, :216-219)
+    h = a + b
+    h /= np.maximum(np.linalg.norm(h, axis=1, keepdims=True), 1e-300)
+    flip = (h @ normal) < 0.0
+    h[flip] = -h[flip]
+    return h
+
+
+@pytest.mark.parametrize("alpha,cos_theta,phi", TR_CASES)
+def test_tr_weak_furnace(O, alpha, cos_theta, phi):  # weak_furnace_test :164-185: int g1(h, wo) d(h.z) / (4 |wo.z|) dwi = 1
+    wo = wi_from(cos_theta, phi)
+    wi, w = sphere_quadrature()
+    h = _h_upper(wi, wo, Z)
+    f = O.tr_g1(alpha, Z, h, wo).astype(np.float64) * O.tr_d(alpha, h[:, 2]).astype(np.float64) / (4.0 * abs(wo[2]))
+    assert abs((f * w).sum() - 1.0) < TR_TOL
+
+
+@pytest.mark.parametrize("alpha,cos_theta,phi", TR_CASES)
+def test_tr_g2_bounded(O, alpha, cos_theta, phi):  # g2_test :187-207: int g2(h, a, b) d(h.z) / (4 |a.z|) db <= 1
+    a = wi_from(cos_theta, phi)
+    b, w = sphere_quadrature()
+    h = _h_upper(a, b, Z)
+    f = O.tr_g2(alpha, Z, h, a, b).astype(np.float64) * O.tr_d(alpha, h[:, 2]).astype(np.float64) / (4.0 * abs(a[2]))
+    integral = (f * w).sum()
+    assert 0.0 < integral <= 1.0 + TR_TOL
+
+
+@pytest.mark.parametrize("normal", [(-0.6, 0.2, 0.5), (0.6, -0.2, -0.7)])  # a.(-normal) < 0 (d = 0) and > 0
+@pytest.mark.parametrize("alpha,cos_theta,phi", TR_CASES)
+def test_tr_g2_bounded_non_local(O, alpha, cos_theta, phi, normal):  # g2_test_non_local :209-230 (one-sided, as there)
+    a = wi_from(cos_theta, phi)
+    normal = unit(normal)
+    b, w = sphere_quadrature()
+    h = _h_upper(a, b, normal)
+    denom = 4.0 * abs(a @ (-normal))
+    f = O.tr_g2(alpha, normal, h, a, b).astype(np.float64) * float(O.tr_d(alpha, [a @ (-normal)])[0]) / denom
+    integral = (f * w).sum() if denom >= 1e-9 else 0.0
+    assert integral <= 1.0 + TR_TOL
