@@ -315,6 +315,99 @@ RT_HD float rt_pow5f(float x)
 }
 
 /* f32::to_radians: self * (PI / 180) evaluated in f32 */
+/* x^y for the output stage's `val.powf(1.0 / gamma)` (crates/output/src/lib.rs:92-95).  Computed in binary64 from IEEE
+ * +, -, *, / and explicit fma only -- log2 by the atanh series on a mantissa in [sqrt(1/2), sqrt(2)), exp2 by a Taylor
+ * polynomial on [-1/2, 1/2] -- so host and device agree bit for bit; the f64 result carries ~1e-15 relative error before the
+ * single rounding to f32 (within 1 ulp of libm's powf; tests/test_detmath.py).  Special cases follow powf. */
+RT_HD double rt_bits_f64(uint64_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __longlong_as_double((long long)u);
+#else
+	double d;
+	memcpy(&d, &u, sizeof d);
+	return d;
+#endif
+}
+RT_HD float rt_powf(float x, float y)
+{
+	if (y == 0.0f || x == 1.0f)
+		return 1.0f;
+	if (x != x || y != y)
+		return x + y; /* NaN */
+	if (x < 0.0f)
+		return rt_bits_f32(0x7FC00000u); /* negative base: NaN for the non-integer exponents of this stage (1/gamma) */
+	if (x == 0.0f)
+		return y > 0.0f ? 0.0f : INFINITY;
+	if (x == INFINITY)
+		return y > 0.0f ? INFINITY : 0.0f;
+	if (y == INFINITY || y == -INFINITY)
+		return ((x > 1.0f) == (y > 0.0f)) ? INFINITY : 0.0f;
+	/* x = m * 2^e, m in [sqrt(1/2), sqrt(2)) */
+	uint32_t bits = rt_f32_bits(x);
+	int e = 0;
+	if ((bits >> 23) == 0u) { /* subnormal: scale by 2^24 (exact) */
+		bits = rt_f32_bits(x * 16777216.0f);
+		e = -24;
+	}
+	e += (int)(bits >> 23) - 127;
+	float m = rt_bits_f32((bits & 0x007FFFFFu) | 0x3F800000u); /* [1, 2) */
+	if (m > 1.41421353816986083984f) {
+		m *= 0.5f;
+		e += 1;
+	}
+	const double md = (double)m;
+	const double f = (md - 1.0) / (md + 1.0); /* |f| <= 0.1716 */
+	const double f2 = f * f;
+	double p = 1.0 / 25.0;
+	p = fma(p, f2, 1.0 / 23.0);
+	p = fma(p, f2, 1.0 / 21.0);
+	p = fma(p, f2, 1.0 / 19.0);
+	p = fma(p, f2, 1.0 / 17.0);
+	p = fma(p, f2, 1.0 / 15.0);
+	p = fma(p, f2, 1.0 / 13.0);
+	p = fma(p, f2, 1.0 / 11.0);
+	p = fma(p, f2, 1.0 / 9.0);
+	p = fma(p, f2, 1.0 / 7.0);
+	p = fma(p, f2, 1.0 / 5.0);
+	p = fma(p, f2, 1.0 / 3.0);
+	p = fma(p, f2, 1.0);
+	const double ln_m = 2.0 * f * p;
+	const double log2_x = (double)e + ln_m * 1.4426950408889634074; /* log2(e) */
+	double z = (double)y * log2_x;
+	if (z > 200.0)
+		z = 200.0; /* beyond f32 range either way: the final conversion gives inf / 0 */
+	if (z < -200.0)
+		z = -200.0;
+	const double n = floor(z + 0.5);
+	const double r = (z - n) * 0.69314718055994530942; /* |r| <= 0.3466 */
+	double q = 1.0 / 87178291200.0; /* 1/14! */
+	q = fma(q, r, 1.0 / 6227020800.0);
+	q = fma(q, r, 1.0 / 479001600.0);
+	q = fma(q, r, 1.0 / 39916800.0);
+	q = fma(q, r, 1.0 / 3628800.0);
+	q = fma(q, r, 1.0 / 362880.0);
+	q = fma(q, r, 1.0 / 40320.0);
+	q = fma(q, r, 1.0 / 5040.0);
+	q = fma(q, r, 1.0 / 720.0);
+	q = fma(q, r, 1.0 / 120.0);
+	q = fma(q, r, 1.0 / 24.0);
+	q = fma(q, r, 1.0 / 6.0);
+	q = fma(q, r, 0.5);
+	q = fma(q, r, 1.0);
+	q = fma(q, r, 1.0);
+	const double scale = rt_bits_f64((uint64_t)((long long)n + 1023) << 52); /* 2^n, n in [-200, 200] */
+	return (float)(q * scale);
+}
+
+/* save_data_to_image's pixel conversion (crates/output/src/lib.rs:92-95): (val.powf(1.0 / gamma) * 255.999) as u8.
+ * Rust's float -> u8 `as` saturates and maps NaN to 0. */
+RT_HD uint8_t rt_quantise_u8(float val, float inv_gamma)
+{
+	const float v = rt_powf(val, inv_gamma) * 255.999f;
+	return !(v > 0.0f) ? (uint8_t)0 : (v >= 255.0f ? (uint8_t)255 : (uint8_t)v);
+}
+
 RT_HD float rt_to_radians(float deg)
 {
 	return deg * (RT_PI / 180.0f);

@@ -751,6 +751,7 @@ int ora_detmath_eval(int32_t which, const float *a, const float *b, uint64_t n, 
 		case 3: out[i] = rt_atan2f(a[i], b[i]); break;
 		case 4: out[i] = rt_tanf(a[i]); break;
 		case 5: out[i] = rt_pow5f(a[i]); break;
+		case 6: out[i] = rt_powf(a[i], b[i]); break;
 		default: return fail(RT_ERR_INVALID_ARGUMENT, "unknown function");
 		}
 	}
@@ -883,6 +884,19 @@ int ora_dist1d_sample_many(const float *values, uint64_t n_values, uint64_t seed
 	ora_ctx_free(&ctx);
 	free(d.cdf);
 	free(d.pdf);
+	return RT_OK;
+}
+
+/* save_data_to_image's pixel conversion  crates/output/src/lib.rs:89-97:
+ *   data.iter().map(|val| (val.powf(1.0 / gamma) * 255.999) as u8)
+ * (powf = the contract's rt_powf; `as u8` saturates, NaN -> 0) */
+int ora_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *out)
+{
+	if (!rgb || !out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	const float inv_gamma = 1.0f / gamma;
+	for (uint64_t i = 0; i < n_values; ++i)
+		out[i] = rt_quantise_u8(rgb[i], inv_gamma);
 	return RT_OK;
 }
 

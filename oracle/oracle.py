@@ -271,6 +271,14 @@ def tr_g2(alpha, normal, h, incoming, outgoing):
     return out
 
 
+def output_rgb8(image, gamma=2.2):
+    """(val.powf(1.0 / gamma) * 255.999) as u8  (crates/output/src/lib.rs:89-97)"""
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    _check(lib().ora_output_rgb8(_p(a, C.c_float), C.c_uint64(a.size), C.c_float(gamma), _p(out, C.c_uint8)))
+    return out
+
+
 def sort_by_indices(values, indices):
     v = np.ascontiguousarray(values, dtype=np.uint64).copy()
     i = np.ascontiguousarray(indices, dtype=np.uint64)

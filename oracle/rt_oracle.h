@@ -83,6 +83,8 @@ int ora_tr_g2_many(float alpha, const float normal[3], const float *h, const flo
                    float *out);
 int ora_dist2d_sample_many(const float *values, uint64_t n_values, uint64_t width, uint64_t seed, uint64_t n, uint32_t *out_x,
                            uint32_t *out_y, float *out_pdf);
+/* the output stage's pixel conversion (crates/output/src/lib.rs:89-97) */
+int ora_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *out);
 int ora_sort_by_indices(uint64_t *values, uint64_t n, const uint64_t *indices);
 /* sky tables as built by Sky::new: cdf rows (res_y x (res_x+1)) then marginal cdf (res_y+1) */
 int ora_sky_tables(const ora_scene *scene, float *row_cdf, float *marginal_cdf);

@@ -244,6 +244,8 @@ EXPORTED_SYMBOLS = [
     "rt_last_launch_info",
     "rt_output_rgb8",
     "rt_output_save",
+    "rt_output_rgb8_device",
+    "rt_render_rgb8",
     "rt_check_hit",
     "rt_check_hit_index",
 ]

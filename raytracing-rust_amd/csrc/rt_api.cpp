@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "../../include/rt_detmath.h"
 #include "rt_build.h"
 #include "rt_types.h"
 
@@ -27,6 +28,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
                          unsigned long long *rays_shot, uint32_t *work_counter);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
+hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
 hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
@@ -91,6 +93,8 @@ struct rt_scene {
 	hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	size_t max_lds = 65536;
 	rt_launch_info last_launch{};
+	uint8_t *d_rgb8 = nullptr; // rt_render_rgb8: the quantised frame
+	size_t d_rgb8_bytes = 0;
 };
 
 template <class T> static int upload(rt_scene *s, const T *src, size_t count, const T **dst)
@@ -156,6 +160,8 @@ void rt_scene_destroy(rt_scene *s)
 		(void)hipFree(p);
 	if (s->d_partial)
 		(void)hipFree(s->d_partial);
+	if (s->d_rgb8)
+		(void)hipFree(s->d_rgb8);
 	for (int b = 0; b < 2; ++b) {
 		if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
 		if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
@@ -697,6 +703,65 @@ int rt_render(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, flo
 	return rc;
 }
 
+int rt_output_rgb8_device(rt_scene *s, const float *d_rgb, uint64_t n_values, float gamma, uint8_t *d_out, void *hip_stream)
+{
+	if (!s || !d_rgb || !d_out)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): this call needs a GPU (rt_output_rgb8 is the host-side conversion)");
+	if (n_values == 0)
+		return RT_OK;
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(launch_quantise(static_cast<hipStream_t>(hip_stream), d_rgb, (size_t)n_values, 1.0f / gamma, d_out));
+	return RT_OK;
+}
+
+int rt_render_rgb8(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, float gamma, uint8_t *out_rgb8, uint64_t *rays_shot)
+{
+	if (!s || !camera || !o)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): this call needs a GPU, there is no CPU fallback");
+	uint64_t n_values = 0;
+	int rc = rt_render_output_floats(o, &n_values);
+	if (rc != RT_OK)
+		return rc;
+	if (n_values == 0) {
+		if (rays_shot)
+			*rays_shot = 0;
+		return RT_OK;
+	}
+	if (!out_rgb8)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	HIP_TRY(hipSetDevice(s->device));
+	rc = ensure_frame_buffers(s, n_values, false);
+	if (rc != RT_OK)
+		return rc;
+	if (n_values > s->d_rgb8_bytes) { // scene-owned byte frame, grown on first use
+		if (s->d_rgb8)
+			(void)hipFree(s->d_rgb8);
+		s->d_rgb8 = nullptr;
+		s->d_rgb8_bytes = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_rgb8), n_values));
+		s->d_rgb8_bytes = n_values;
+	}
+	float *d_frame = s->d_prog[0];
+	rc = rt_render_device(s, camera, o, d_frame, reinterpret_cast<uint64_t *>(s->d_rays), s->stream);
+	if (rc != RT_OK)
+		return rc;
+	// the output stage runs where the frame is: the float frame never crosses PCIe, one byte per value does
+	hipError_t e = launch_quantise(s->stream, d_frame, (size_t)n_values, 1.0f / gamma, s->d_rgb8);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(out_rgb8, s->d_rgb8, n_values, hipMemcpyDeviceToHost, s->stream);
+	if (e == hipSuccess && rays_shot)
+		e = hipMemcpyAsync(rays_shot, s->d_rays, sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(s->stream);
+	if (e != hipSuccess)
+		return hip_fail(e, "render_rgb8");
+	return RT_OK;
+}
+
 int rt_sample_image(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, uint64_t batch, rt_presentation_update update, void *data)
 {
 	if (!s || !camera || !o)
@@ -847,10 +912,8 @@ int rt_output_rgb8(const float *rgb, uint64_t n_values, float gamma, uint8_t *ou
 	if (!rgb || !out)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	const float inv_gamma = 1.0f / gamma;
-	for (uint64_t i = 0; i < n_values; ++i) {
-		const float v = std::pow(rgb[i], inv_gamma) * 255.999f; // val.powf(1.0 / gamma) * 255.999
-		out[i] = !(v > 0.0f) ? 0 : (v >= 255.0f ? 255 : (uint8_t)v); // `as u8`: saturating, NaN -> 0
-	}
+	for (uint64_t i = 0; i < n_values; ++i)
+		out[i] = rt_quantise_u8(rgb[i], inv_gamma); // (val.powf(1.0 / gamma) * 255.999) as u8, powf = the contract's rt_powf
 	return RT_OK;
 }
 

@@ -906,6 +906,33 @@ hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned lon
 	return hipGetLastError();
 }
 
+// ---- output stage on the device: save_data_to_image's `(val.powf(1.0 / gamma) * 255.999) as u8`
+// (crates/output/src/lib.rs:89-97) applied where the frame lives, so a caller that wants an 8-bit image copies
+// W*H*3 bytes over PCIe instead of W*H*12.  Streaming: 4 values per lane, one dwordx4 load and one dword store. ----
+__global__ __launch_bounds__(256) void quantise_kernel(const float *__restrict__ rgb, size_t n_values, float inv_gamma, uint8_t *__restrict__ out)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	const size_t n4 = n_values / 4;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+		const float4 v = reinterpret_cast<const float4 *>(rgb)[i];
+		const uint32_t q = (uint32_t)rt_quantise_u8(v.x, inv_gamma) | ((uint32_t)rt_quantise_u8(v.y, inv_gamma) << 8) |
+		                   ((uint32_t)rt_quantise_u8(v.z, inv_gamma) << 16) | ((uint32_t)rt_quantise_u8(v.w, inv_gamma) << 24);
+		reinterpret_cast<uint32_t *>(out)[i] = q;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n_values & 3))
+		out[n4 * 4 + threadIdx.x] = rt_quantise_u8(rgb[n4 * 4 + threadIdx.x], inv_gamma);
+}
+hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out)
+{
+	size_t blocks = (n_values / 4 + 255) / 256;
+	if (blocks < 1)
+		blocks = 1;
+	if (blocks > 8192)
+		blocks = 8192;
+	hipLaunchKernelGGL(quantise_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, rgb, n_values, inv_gamma, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out)
 {
 	hipLaunchKernelGGL(combine_chunks_kernel, dim3((P.n_work + 255u) / 256u), dim3(256), 0, stream, P, partial, out);

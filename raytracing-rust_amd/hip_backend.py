@@ -151,6 +151,19 @@ class HipScene:
             out = out.reshape(-1, 3)
         return out, rays.value
 
+    def render_rgb8(self, camera, opts, gamma=2.2):
+        """rt_render + the output stage on the device: the 8-bit image save_data_to_image would write (lib.rs:89-97)."""
+        n = C.c_uint64()
+        _check(lib().rt_render_output_floats(C.byref(opts), C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        rays = C.c_uint64()
+        _check(lib().rt_render_rgb8(self._h, C.byref(camera), C.byref(opts), C.c_float(gamma), _p(out, C.c_uint8), C.byref(rays)))
+        return (out.reshape(opts.height, opts.width, 3) if opts.output_layout == abi.RT_LAYOUT_FRAME else out.reshape(-1, 3)), rays.value
+
+    def output_rgb8_device(self, d_rgb_ptr, n_values, d_out_ptr, gamma=2.2, stream=0):
+        _check(lib().rt_output_rgb8_device(self._h, C.c_void_p(d_rgb_ptr), C.c_uint64(n_values), C.c_float(gamma), C.c_void_p(d_out_ptr),
+                                           C.c_void_p(stream)))
+
     def render_device(self, camera, opts, d_out_ptr, d_rays_ptr=None, stream=0):
         """Asynchronous render into device memory (raw pointers, e.g. torch.Tensor.data_ptr())."""
         _check(lib().rt_render_device(self._h, C.byref(camera), C.byref(opts), C.c_void_p(d_out_ptr),

@@ -84,13 +84,15 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     summary["write_bytes"] = c["WRITE_SIZE"] * 1024.0
 if "TCC_EA0_RDREQ_sum" in c:
     rd, rd32, bub = c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_BUBBLE_sum", 0.0)
+    # profiles/r02_fabric_counter_calibration.txt: on gfx950 every non-32B fabric read request is one 128-byte L2 line
+    # (streaming control: 2 GiB / 16.78 M requests; random 64- and 128-byte records: one request per record either way);
+    # counter_defs' FETCH_SIZE formula tallies them at 64 because TCC_BUBBLE stays 0
     summary["fabric_read_requests"] = {"all": rd, "32B": rd32, "128B_bubble": bub, "to_dram": c.get("TCC_EA0_RDREQ_DRAM_sum"),
-                                       "bytes_if_64B_each": (rd - rd32) * 64 + rd32 * 32,
+                                       "bytes_at_128B_lines": (rd - rd32) * 128 + rd32 * 32,
                                        "bytes_formula_of_counter_defs": bub * 128 + (rd - bub - rd32) * 64 + rd32 * 32}
 if "TCC_HIT_sum" in c:
     summary["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     summary["l2_miss_bytes_at_128B_lines"] = c["TCC_MISS_sum"] * 128.0
-    summary["l2_miss_bytes_at_64B"] = c["TCC_MISS_sum"] * 64.0
 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
     summary["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
 if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
@@ -123,9 +125,10 @@ if "fetch_bytes_as_reported" in summary:
     # fabric bytes: every L2 miss moves one 128-byte line when requests are 128-byte (streaming), 64 when they are
     # 64-byte; the request-size counters decide (fabric_read_requests).  Default to the counter_defs formula.
     fr = summary.get("fabric_read_requests")
-    rd_bytes = fr["bytes_formula_of_counter_defs"] if fr else summary["fetch_bytes_as_reported"]
+    rd_bytes = fr["bytes_at_128B_lines"] if fr else 2.0 * summary["fetch_bytes_as_reported"]
     entry["hbm_bytes_per_launch"] = rd_bytes + summary["write_bytes"]
-    entry["hbm_bytes_note"] = "fabric (Infinity Cache + HBM) bytes: read requests by size (TCC_EA0_RDREQ split) + WRITE_SIZE"
+    entry["hbm_bytes_note"] = ("fabric (Infinity Cache + HBM) bytes: TCC_EA0_RDREQ x 128-byte lines (= 2 x FETCH_SIZE, "
+                               "profiles/r02_fabric_counter_calibration.txt) + WRITE_SIZE")
 kc[workload] = entry
 json.dump(kc, open(kp, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in summary.items() if k not in ("counters_per_launch", "command")}, indent=1))

@@ -125,3 +125,22 @@ def test_tan_pow5(O):
     assert ulp_error(O.detmath(4, x), np.tan(x.astype(np.float64))).max() <= 4.0
     x = np.linspace(0, 1, 10001).astype(np.float32)
     assert ulp_error(O.detmath(5, x), x.astype(np.float64) ** 5).max() <= 3.0
+
+
+def test_powf_against_float64(O):
+    """rt_powf (the output stage's val.powf(1/gamma), crates/output/src/lib.rs:92-95): within 1 ulp of the correctly
+    rounded result over colour-like bases and display gammas, exact on the special cases of powf."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 4, 200000), 10.0 ** rng.uniform(-38, 38, 50000), rng.uniform(0, 1e-40, 1000)]).astype(np.float32)
+    for y in (1 / 2.2, 1 / 2.4, 0.5, 1.0, 2.2, 3.0, -0.75):
+        yy = np.full_like(x, np.float32(y))
+        got = O.detmath(6, x, yy)
+        with np.errstate(over="ignore", divide="ignore"):
+            exact = x.astype(np.float64) ** np.float64(np.float32(y))
+        fin = np.isfinite(exact) & (exact < 3e38) & (exact > 1e-37)
+        assert ulp_error(got[fin], exact[fin]).max() <= 1.0
+    sp_x = np.array([0.0, 0.0, 1.0, np.inf, np.inf, -1.0, np.nan, 2.0, 0.5, 2.0, 0.5, 5.0], dtype=np.float32)
+    sp_y = np.array([0.5, -0.5, np.nan, 0.5, -0.5, 0.5, 0.5, np.inf, np.inf, -np.inf, -np.inf, 0.0], dtype=np.float32)
+    want = np.array([0.0, np.inf, 1.0, np.inf, 0.0, np.nan, np.nan, np.inf, 0.0, 0.0, np.inf, 1.0], dtype=np.float32)
+    got = O.detmath(6, sp_x, sp_y)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0))

@@ -24,6 +24,16 @@ def test_rgb8_conversion(hb):
     assert np.array_equal(hb.output_rgb8(img, 1.0), np.clip(np.floor(img * np.float32(255.999)), 0, 255).astype(np.uint8))
 
 
+def test_rgb8_host_conversion_equals_the_oracle_twin(hb, O):
+    """f3: the product's host conversion and the oracle's restatement of lib.rs:92-95 share the contract's rt_powf, so
+    they must agree byte for byte (special values included); the GPU twin is checked in test_gpu_parity.py."""
+    rng = np.random.default_rng(3)
+    img = np.concatenate([rng.uniform(-0.2, 1.5, 300000), 10.0 ** rng.uniform(-30, 30, 5000),
+                          [np.nan, np.inf, -np.inf, 0.0, -0.0, 1.0, 255.0 / 255.999]]).astype(np.float32)
+    for gamma in (2.2, 1.0, 2.4, 0.8):
+        assert np.array_equal(hb.output_rgb8(img, gamma), O.output_rgb8(img, gamma))
+
+
 def _read_png(path):
     data = open(path, "rb").read()
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
