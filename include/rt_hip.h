@@ -265,8 +265,11 @@ int rt_scene_set_traversal(rt_scene *scene, int mode);
  *                         only raise it
  *   RT_TUNE_SCENE_IN_LDS  1 (default): tiny scenes are staged whole into LDS; 0: read from HBM/L2
  *   RT_TUNE_SCHEDULE      -1 automatic, 0 coarse (two voted super-phases), 1 fine (every step of the
- *                         per-lane state machine is voted; implies the pruned walk) */
-typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3 } rt_tuning_key;
+ *                         per-lane state machine is voted; implies the pruned walk)
+ *   RT_TUNE_WALK          0 automatic: pruned walks use the wide (four-child, 128-byte-node) regrouping of the
+ *                         reference tree for regular rays and the two-child tree for the rest; 1: the two-child
+ *                         tree for every ray */
+typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3, RT_TUNE_WALK = 4 } rt_tuning_key;
 int rt_scene_set_tuning(rt_scene *scene, int key, int value);
 
 /* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----

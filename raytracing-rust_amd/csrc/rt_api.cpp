@@ -241,6 +241,9 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 		}
 	}
 	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
+	if (!h.dev_nodes4.empty()) { // hipMalloc aligns far beyond the 128 bytes a DevNode4 line needs
+		if ((rc = upload(s, h.dev_nodes4.data(), h.dev_nodes4.size(), &D.nodes4)) != RT_OK) return bail(rc);
+	}
 	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.prim_rank.data(), h.prim_rank.size(), &D.prim_rank)) != RT_OK) return bail(rc);
@@ -289,6 +292,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	D.n_materials = (uint32_t)h.materials.size();
 	D.n_textures = (uint32_t)h.textures.size();
 	D.root_ref = h.root_ref;
+	D.root4_ref = h.root4_ref;
+	D.n_nodes4 = (uint32_t)h.dev_nodes4.size();
 	std::memcpy(D.root_min, h.root_min, sizeof D.root_min);
 	std::memcpy(D.root_max, h.root_max, sizeof D.root_max);
 	D.stack_depth = h.stack_depth;
@@ -361,6 +366,11 @@ int rt_scene_set_tuning(rt_scene *s, int key, int value)
 		return RT_OK;
 	case RT_TUNE_SCENE_IN_LDS:
 		s->scene_lds_allowed = value != 0;
+		return RT_OK;
+	case RT_TUNE_WALK:
+		if (value < 0 || value > 1)
+			return fail(RT_ERR_INVALID_ARGUMENT, "walk must be 0 (automatic) or 1 (two-child walk for every ray)");
+		s->dev.narrow_only = (uint32_t)value;
 		return RT_OK;
 	default:
 		return fail(RT_ERR_INVALID_ARGUMENT, "unknown tuning key");
@@ -578,8 +588,10 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	// pay, t-pruned otherwise; both select the same winner (rt_intersect.h)
 	// and how finely the wave votes: measured crossovers on random sphere scenes (tests/probes/gpu_crossover_probe.py)
 	bool prune = s->traversal_mode == -1 ? s->dev.n_prims > kPruneAbove : s->traversal_mode == 1;
-	const bool fine = s->schedule_mode == -1 ? (prune && s->dev.n_prims > (s->dev.has_triangles ? kFineAboveTriangles : kFineAboveSpheres))
-	                                         : s->schedule_mode == 1;
+	// the fine schedule walks the wide tree: scenes without one (non-finite bounds, a single leaf) stay coarse
+	const bool fine = s->dev.nodes4 != nullptr &&
+	                  (s->schedule_mode == -1 ? (prune && s->dev.n_prims > (s->dev.has_triangles ? kFineAboveTriangles : kFineAboveSpheres))
+	                                          : s->schedule_mode == 1);
 	if (fine)
 		prune = true;
 	P.prune = prune ? 1 : 0;

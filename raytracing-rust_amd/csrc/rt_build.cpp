@@ -578,13 +578,21 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		err = "more than 2^26 primitives: leaf references hold 26-bit slots";
 		return RT_ERR_UNSUPPORTED;
 	}
-	auto leaf_ref = [&](const HostNode &leaf) -> uint32_t {
-		if (leaf.number_primitives <= kLeafInlineMax)
-			return kLeafFlag | ((uint32_t)leaf.number_primitives << 26) | (uint32_t)leaf.primitive_offset;
-		hs.big_leaves.push_back((uint32_t)leaf.primitive_offset);
-		hs.big_leaves.push_back((uint32_t)leaf.number_primitives);
-		return kLeafFlag | (uint32_t)(hs.big_leaves.size() / 2 - 1);
-	};
+	// one reference per leaf, made once and serially (big leaves append to a table), shared by both device trees
+	std::vector<uint32_t> leaf_ref_of(hs.nodes.size(), 0u);
+	for (size_t i = 0; i < hs.nodes.size(); ++i) {
+		const HostNode &leaf = hs.nodes[i];
+		if (leaf.child[0] >= 0)
+			continue;
+		if (leaf.number_primitives <= kLeafInlineMax) {
+			leaf_ref_of[i] = kLeafFlag | ((uint32_t)leaf.number_primitives << 26) | (uint32_t)leaf.primitive_offset;
+		} else {
+			hs.big_leaves.push_back((uint32_t)leaf.primitive_offset);
+			hs.big_leaves.push_back((uint32_t)leaf.number_primitives);
+			leaf_ref_of[i] = kLeafFlag | (uint32_t)(hs.big_leaves.size() / 2 - 1);
+		}
+	}
+	auto leaf_ref = [&](const HostNode &leaf) -> uint32_t { return leaf_ref_of[(size_t)(&leaf - hs.nodes.data())]; };
 	uint32_t max_depth = 1;
 	if (root.child[0] >= 0) {
 		std::vector<int64_t> dev_index(hs.nodes.size(), -1);
@@ -627,6 +635,90 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		hs.root_ref = leaf_ref(root);
 	}
 	hs.stack_depth = max_depth + 1;
+
+	// ---- wide tree: the reference tree collapsed to up to four children per node (rt_types.h DevNode4).
+	// A node's children start as its two reference children; the inner child with the largest surface area is
+	// replaced by ITS two children until there are four (or only leaves are left).  Child boxes are the reference
+	// nodes' own boxes, leaves are the reference's leaves: rt_intersect.h explains why the walk over this tree finds
+	// exactly the reference's candidates.  Built only when every bound is finite (the argument needs that). ----
+	hs.dev_nodes4.clear();
+	hs.root4_ref = hs.root_ref;
+	bool finite_bounds = true;
+	for (const HostNode &hn : hs.nodes)
+		for (int k = 0; k < 3; ++k)
+			finite_bounds = finite_bounds && std::isfinite(hn.min[k]) && std::isfinite(hn.max[k]);
+	if (finite_bounds && root.child[0] >= 0) {
+		auto area = [&](const HostNode &b) {
+			const double dx = (double)b.max[0] - b.min[0], dy = (double)b.max[1] - b.min[1], dz = (double)b.max[2] - b.min[2];
+			return dx * dy + dy * dz + dz * dx;
+		};
+		struct Pending { uint64_t host; uint32_t wide; uint32_t need; };
+		std::vector<Pending> todo;
+		hs.dev_nodes4.reserve(hs.nodes.size() / 3 + 16);
+		hs.dev_nodes4.emplace_back();
+		hs.root4_ref = 0;
+		todo.push_back({0, 0, 0});
+		uint32_t wide_stack = 1;
+		while (!todo.empty()) {
+			const Pending it = todo.back();
+			todo.pop_back();
+			uint64_t kids[4];
+			int n_kids = 2;
+			kids[0] = (uint64_t)hs.nodes[it.host].child[0];
+			kids[1] = (uint64_t)hs.nodes[it.host].child[1];
+			while (n_kids < 4) {
+				int open = -1;
+				double best = -1.0;
+				for (int k = 0; k < n_kids; ++k)
+					if (hs.nodes[kids[k]].child[0] >= 0 && area(hs.nodes[kids[k]]) > best) {
+						best = area(hs.nodes[kids[k]]);
+						open = k;
+					}
+				if (open < 0)
+					break;
+				const HostNode &o = hs.nodes[kids[open]];
+				for (int k = n_kids; k > open + 1; --k) // keep the reference's left-to-right order
+					kids[k] = kids[k - 1];
+				kids[open] = (uint64_t)o.child[0];
+				kids[open + 1] = (uint64_t)o.child[1];
+				++n_kids;
+			}
+			// a depth-first walk that descends into one child leaves at most n_kids - 1 siblings on its stack
+			const uint32_t need_below = it.need + (uint32_t)(n_kids - 1);
+			wide_stack = std::max(wide_stack, need_below + 1);
+			DevNode4 dn;
+			std::memset(&dn, 0, sizeof dn);
+			for (int k = 0; k < 4; ++k) {
+				if (k >= n_kids) {
+					dn.child[k] = kRefNone;
+					continue;
+				}
+				const HostNode &ch = hs.nodes[kids[k]];
+				float e = 0.0f;
+				for (int a = 0; a < 3; ++a) {
+					dn.lo[a][k] = ch.min[a];
+					dn.hi[a][k] = ch.max[a];
+				}
+				e = (ch.max[0] - ch.min[0]) + (ch.max[1] - ch.min[1]) + (ch.max[2] - ch.min[2]); // box_extent_l1's own order
+				dn.ext[k] = e;
+				if (ch.child[0] >= 0) {
+					const uint32_t w = (uint32_t)hs.dev_nodes4.size();
+					hs.dev_nodes4.emplace_back();
+					dn.child[k] = w;
+					todo.push_back({kids[k], w, need_below});
+				} else {
+					dn.child[k] = leaf_ref(ch);
+				}
+			}
+			hs.dev_nodes4[it.wide] = dn;
+		}
+		if (wide_stack > 96) { // would not fit the per-lane LDS stack: keep the two-child tree only
+			hs.dev_nodes4.clear();
+			hs.root4_ref = hs.root_ref;
+		} else {
+			hs.stack_depth = std::max(hs.stack_depth, wide_stack);
+		}
+	}
 	if (hs.stack_depth > 96) {
 		err = "BVH deeper than 95 inner levels: the per-lane LDS traversal stack does not fit";
 		return RT_ERR_UNSUPPORTED;

@@ -381,6 +381,66 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uin
 	return stk[sp * kStackStride];
 }
 
+// ---- the wide walk ----
+// WHY ANOTHER TREE RETURNS THE SAME HITS.  The reference tests a leaf's primitives iff the leaf's box and every
+// ancestor's box pass AABB::does_int (mod.rs:199-224).  A node's box is the exact union of its primitives' boxes
+// (mod.rs:105-108), so an ancestor's box contains the leaf's box exactly, and for a REGULAR ray -- every component of
+// origin and 1/direction finite, which makes every (bound - origin) * inverse in the slab test a non-NaN value -- the
+// slab test is monotone in the bounds: each IEEE operation in it is monotone, and on a box that is hit every axis has
+// near = t1 and far = t2 * widen, so a box containing a hit box has tmin no larger and tmax no smaller and is hit too.
+// Hence for regular rays "leaf and all its ancestors hit" == "the leaf's own box is hit": the reference's candidate
+// leaves are exactly the leaves whose own box passes does_int, whatever hierarchy leads to them.  The wide tree keeps
+// the reference's leaves and boxes and only regroups them (four children per 128-byte node), and the walk tests every
+// child box with the reference's predicate, so it reaches exactly those leaves; the winner among their primitives is
+// chosen by the same (t, BFS rank) rule.  Irregular rays (a zero direction component gives an infinite inverse, and
+// 0 * inf = NaN is IGNORED by Rust's min/max, which breaks monotonicity for flat boxes) take the two-child walk, which
+// tests every ancestor as the reference does.  Scenes with non-finite bounds get no wide tree at all.
+__device__ __forceinline__ bool ray_is_regular(const Ray &r)
+{
+	// finite - finite and finite * 0 stay finite; any NaN or inf operand makes the sum NaN or inf
+	const float probe = (r.o.x + r.o.y + r.o.z) * 0.0f + (fabsf(r.inv.x) + fabsf(r.inv.y) + fabsf(r.inv.z));
+	return probe < INFINITY; // false for NaN too
+}
+
+// One step of the wide descent: fetch the 128-byte node, test its (up to) four child boxes with the reference's
+// predicate, prune, go to the nearest surviving child and push the others farthest first.
+template <bool PRUNE>
+__device__ __forceinline__ uint32_t descend4(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid, float t_limit)
+{
+	const float4 *q = reinterpret_cast<const float4 *>(&S.nodes4[node]);
+	const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+	const float4 refs = q[6], ext = q[7];
+	const float lo[4][3] = {{lox.x, loy.x, loz.x}, {lox.y, loy.y, loz.y}, {lox.z, loy.z, loz.z}, {lox.w, loy.w, loz.w}};
+	const float hi[4][3] = {{hix.x, hiy.x, hiz.x}, {hix.y, hiy.y, hiz.y}, {hix.z, hiy.z, hiz.z}, {hix.w, hiy.w, hiz.w}};
+	const uint32_t ref[4] = {__float_as_uint(refs.x), __float_as_uint(refs.y), __float_as_uint(refs.z), __float_as_uint(refs.w)};
+	const float ex[4] = {ext.x, ext.y, ext.z, ext.w};
+	// sort key: entry distance clamped to >= 0 as ordered bits, child slot in the two low bits (the order is a
+	// heuristic: it decides how soon pruning bites, never what is found); 0xFFFFFFFF = not to be visited
+	uint32_t key[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float t;
+		bool h = ref[c] != kRefNone && aabb_does_int(lo[c], hi[c], r, t);
+		if (PRUNE && limit_valid && h && t - kPruneSlack * (fabsf(t) + fabsf(t_limit) + ex[c]) > t_limit)
+			h = false;
+		key[c] = h ? ((__float_as_uint(fmax_(t, 0.0f)) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+	}
+#define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
+	RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+	auto ref_of = [&](uint32_t k) { const uint32_t c = k & 3u; return c == 0u ? ref[0] : (c == 1u ? ref[1] : (c == 2u ? ref[2] : ref[3])); };
+	if (key[0] == 0xFFFFFFFFu) { // nothing to descend into
+		if (sp == 0)
+			return kRefDone;
+		--sp;
+		return stk[sp * kStackStride];
+	}
+	if (key[3] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[3]); ++sp; }
+	if (key[2] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[2]); ++sp; }
+	if (key[1] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[1]); ++sp; }
+	return ref_of(key[0]);
+}
+
 // The root test of Bvh::get_intersection_candidates (mod.rs:203-210).  It decides something only when the
 // root is a leaf: an inner root's bounds contain both children's, and the slab test is monotone in the
 // bounds (each t interval of the larger box contains the smaller box's; a NaN from 0 * inf is ignored by
@@ -462,10 +522,12 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 		return;
 	}
 	int sp = 0;
-	uint32_t node = S.root_ref;
+	const bool wide = PRUNE && S.nodes4 != nullptr && S.narrow_only == 0u && ray_is_regular(r);
+	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
+			node = wide ? descend4<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t)
+			            : descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
 		closest_in_leaf<F>(S, r, node, best_t, best_prim);
@@ -499,10 +561,11 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 		return occluded;
 	}
 	int sp = 0;
-	uint32_t node = S.root_ref;
+	const bool wide = PRUNE && S.nodes4 != nullptr && S.narrow_only == 0u && ray_is_regular(r);
+	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
+			node = wide ? descend4<PRUNE>(S, r, node, stk, sp, limited, t_limit) : descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
 		if (any_in_leaf<F>(S, r, node, t_limit, skip))

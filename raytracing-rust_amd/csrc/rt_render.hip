@@ -46,9 +46,10 @@ enum : int {
 	PH_SHADE = 3,
 	PH_LIGHT = 4,
 	PH_SCATTER = 5,
-	PH_COUNT = 6,
-	PH_NEED_PIXEL = 6, // served at the top of every iteration (one atomic per wave), not voted
-	PH_DONE = 7
+	PH_NARROW = 6,     // fine schedule only: an irregular ray (rt_intersect.h) runs the two-child walk to its end
+	PH_COUNT = 7,
+	PH_NEED_PIXEL = 7, // served at the top of every iteration (one atomic per wave), not voted
+	PH_DONE = 8
 };
 
 // coarse schedule: the LIGHT super-phase runs once this many lanes of the wave wait for it
@@ -264,12 +265,14 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			ph = PH_NODE;
 			return;
 		}
-		if (!root_box_misses(S, ray)) {
-			node = S.root_ref;
-			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
-		} else {
+		if (root_box_misses(S, ray)) {
 			node = kRefDone;
 			ph = shadow ? PH_SCATTER : PH_SHADE;
+		} else if (S.narrow_only != 0u || !ray_is_regular(ray)) {
+			ph = PH_NARROW; // a zero direction component or a non-finite origin: only the two-child walk is exact for it
+		} else {
+			node = S.root4_ref; // the fine schedule walks the wide tree (the host selects it only when one exists)
+			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
 		}
 	};
 	// the walk moved to `node` (inner, leaf or finished): choose the lane's next phase
@@ -318,7 +321,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	};
 
 #ifdef RT_STATS
-	unsigned long long st_lane_nodes = 0, st_lane_prims = 0, st_lane_maxsp = 0, st_lane_dead[3] = {0, 0, 0};
+	unsigned long long st_lane_nodes = 0, st_lane_prims = 0, st_lane_maxsp = 0;
 #endif
 	// NODE -- one inner-node step: Bvh::get_intersection_candidates' loop body (mod.rs:203-221)
 	auto do_node = [&]() {
@@ -328,11 +331,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			st_lane_maxsp = (unsigned long long)sp;
 #endif
 		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
-#ifdef RT_STATS
-		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t, st_lane_dead);
-#else
-		node = descend<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
-#endif
+		node = descend4<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
 		after_step();
 	
 	};
@@ -598,6 +597,20 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	
 	};
 
+	// NARROW -- fine schedule, irregular ray: the whole walk over the two-child tree, here and now (rare: a
+	// direction with an exactly zero component).  trace_closest / trace_any pick that tree for such rays themselves.
+	auto do_narrow = [&]() {
+		if (any_hit) {
+			best_prim = trace_any<F, PRUNE>(S, S_global, ray, stk, PL.t_limit, PL.skip) ? 0u : kNoPrim;
+			ph = PH_SCATTER;
+		} else {
+			trace_closest<F, PRUNE>(S, S_global, ray, stk, best_t, best_prim);
+			ph = PH_SHADE;
+		}
+		node = kRefDone;
+		sp = 0;
+	};
+
 	// coarse schedule: run the pending walk of this lane to its end with the tight while-while loops
 	// of rt_intersect.h (closest walk in the TRACE super-phase, shadow walk in the LIGHT super-phase)
 	auto walk_closest_pending = [&]() {
@@ -684,7 +697,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			uint32_t best_n = 0;
 #pragma unroll
 			for (int k = PH_COUNT - 1; k >= 0; --k) {
-				if (k != PH_NODE && run < 0 && cnt[k] >= (k == PH_LEAF ? kDrainLanes : kDrainLanesHeavy)) {
+				if (k != PH_NODE && run < 0 && cnt[k] >= (k == PH_NARROW ? 1u : (k == PH_LEAF ? kDrainLanes : kDrainLanesHeavy))) {
 					run = k;
 					best_n = cnt[k];
 				}
@@ -716,7 +729,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 #ifdef RT_STATS
 			if (lane == 0u) { // wall-clock share per fine phase: slot 6 = vote + work acquisition, 0..5 = the phase run last
 				const unsigned long long now_ = wall_clock64();
-				st_fine_clock[6] += now_ - st_mark;
+				st_fine_clock[PH_COUNT] += now_ - st_mark;
 				st_mark = now_;
 			}
 #endif
@@ -738,6 +751,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			} else if (run == PH_LIGHT) {
 				if (ph == PH_LIGHT)
 					do_light(PL, ray);
+			} else if (run == PH_NARROW) {
+				if (ph == PH_NARROW)
+					do_narrow();
 			} else {
 				if (ph == PH_SCATTER)
 					do_scatter(PL, ray);
@@ -828,9 +844,6 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	atomicAdd(&g_stats[20], st_lane_nodes); // lane-level node steps and primitive tests of the fine schedule
 	atomicAdd(&g_stats[21], st_lane_prims);
 	atomicMax(&g_stats[22], st_lane_maxsp);
-	atomicAdd(&g_stats[23], st_lane_dead[0]); // node visits that led nowhere / had a hit child pruned / had every hit child pruned
-	atomicAdd(&g_stats[24], st_lane_dead[1]);
-	atomicAdd(&g_stats[25], st_lane_dead[2]);
 	if (lane == 0u) {
 		for (int k = 0; k < 9; ++k)
 			atomicAdd(&g_stats[40 + k], st_sect[k]);

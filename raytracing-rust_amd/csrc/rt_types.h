@@ -46,6 +46,21 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 
+// Wide node: up to four children of a collapsed subtree of the reference tree, one 128-byte record = one L2 line
+// (L1->L2 requests, L2 misses and fabric requests are all per 128-byte line on this chip:
+// profiles/r02_fabric_counter_calibration.txt -- a 64-byte two-child node costs the same line and wastes half of
+// it).  Bounds are the children's EXACT reference boxes, stored per axis for the four children (SoA), so a step is
+// eight dwordx4 loads of one line.  `ext` = (max-min) summed over the axes per child (what the prune test needs),
+// absent children have child == kRefNone.  Why walking this tree returns the reference's hits: rt_intersect.h.
+constexpr uint32_t kRefNone = 0x7FFFFFFEu;
+struct alignas(128) DevNode4 {
+	float lo[3][4];
+	float hi[3][4];
+	uint32_t child[4];
+	float ext[4];
+};
+static_assert(sizeof(DevNode4) == 128, "DevNode4 must be one 128-byte line");
+
 enum : uint32_t { kPrimSphere = 0, kPrimTriangle = 1, kPrimMeshTriangle = 2 };
 
 // sphere:   a = (centre.xyz, meta)  b = (radius, 0, 0, 0)   c unused
@@ -117,7 +132,11 @@ struct DevScene {
 	const uint32_t *blob;
 	uint32_t blob_bytes;
 	uint32_t off_nodes, off_prims, off_shade, off_rank, off_materials, off_textures, off_lights, off_big_leaves;
-	uint32_t stack_depth;      // traversal stack entries per lane (tree depth + 1)
+	uint32_t stack_depth;      // traversal stack entries per lane (enough for the two-child AND the wide walk)
+	const DevNode4 *nodes4;    // wide tree (null: none was built, e.g. non-finite bounds)
+	uint32_t root4_ref;        // child-style reference to its root
+	uint32_t n_nodes4;
+	uint32_t narrow_only;      // RT_TUNE_WALK = 1: every ray takes the two-child walk (tests, A/B measurements)
 	uint32_t has_triangles;
 	DevSky sky;
 };
