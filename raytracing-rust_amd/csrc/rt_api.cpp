@@ -243,6 +243,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
 	if (!h.dev_nodes4.empty()) { // hipMalloc aligns far beyond the 128 bytes a DevNode4 line needs
 		if ((rc = upload(s, h.dev_nodes4.data(), h.dev_nodes4.size(), &D.nodes4)) != RT_OK) return bail(rc);
+		if ((rc = upload(s, h.leaf_box.data(), h.leaf_box.size(), &D.leaf_box)) != RT_OK) return bail(rc);
 	}
 	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);

@@ -636,18 +636,22 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 	}
 	hs.stack_depth = max_depth + 1;
 
-	// ---- wide tree: the reference tree collapsed to up to four children per node (rt_types.h DevNode4).
+	// ---- wide tree: the reference tree collapsed to up to four children per node (rt_types.h DevNodeQ4).
 	// A node's children start as its two reference children; the inner child with the largest surface area is
-	// replaced by ITS two children until there are four (or only leaves are left).  Child boxes are the reference
-	// nodes' own boxes, leaves are the reference's leaves: rt_intersect.h explains why the walk over this tree finds
-	// exactly the reference's candidates.  Built only when every bound is finite (the argument needs that). ----
+	// replaced by ITS two children until there are four (or only leaves are left).  Leaves are the reference's leaves.
+	// Child boxes go onto a per-node grid, origin + q * 2^e with q in 0..255, rounded outward in exact (double)
+	// arithmetic, so the stored box CONTAINS the reference box as a set of real numbers: the walk over it visits a
+	// superset of the reference's nodes, and the leaf's exact box (leaf_box) decides candidacy (rt_intersect.h).
+	// Built only when every bound is finite and of magnitude <= 2^60 (the regular-ray argument needs products of
+	// bounds and inverse directions to stay finite). ----
 	hs.dev_nodes4.clear();
+	hs.leaf_box.clear();
 	hs.root4_ref = hs.root_ref;
-	bool finite_bounds = true;
+	bool tame_bounds = true;
 	for (const HostNode &hn : hs.nodes)
 		for (int k = 0; k < 3; ++k)
-			finite_bounds = finite_bounds && std::isfinite(hn.min[k]) && std::isfinite(hn.max[k]);
-	if (finite_bounds && root.child[0] >= 0) {
+			tame_bounds = tame_bounds && std::fabs(hn.min[k]) <= 0x1p60f && std::fabs(hn.max[k]) <= 0x1p60f; // false for NaN
+	if (tame_bounds && root.child[0] >= 0) {
 		auto area = [&](const HostNode &b) {
 			const double dx = (double)b.max[0] - b.min[0], dy = (double)b.max[1] - b.min[1], dz = (double)b.max[2] - b.min[2];
 			return dx * dy + dy * dz + dz * dx;
@@ -659,7 +663,8 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		hs.root4_ref = 0;
 		todo.push_back({0, 0, 0});
 		uint32_t wide_stack = 1;
-		while (!todo.empty()) {
+		bool ok = true;
+		while (!todo.empty() && ok) {
 			const Pending it = todo.back();
 			todo.pop_back();
 			uint64_t kids[4];
@@ -686,21 +691,51 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			// a depth-first walk that descends into one child leaves at most n_kids - 1 siblings on its stack
 			const uint32_t need_below = it.need + (uint32_t)(n_kids - 1);
 			wide_stack = std::max(wide_stack, need_below + 1);
-			DevNode4 dn;
+			DevNodeQ4 dn;
 			std::memset(&dn, 0, sizeof dn);
-			for (int k = 0; k < 4; ++k) {
+			const HostNode &self = hs.nodes[it.host]; // contains every child exactly (mod.rs:105-108)
+			for (int a = 0; a < 3; ++a) {
+				dn.origin[a] = self.min[a];
+				// smallest power-of-two step with origin + 255 * step >= max (all in double: f32 bounds <= 2^60 are exact there)
+				const double extent = (double)self.max[a] - (double)self.min[a];
+				int e = -126;
+				if (extent > 0.0) {
+					int ex;
+					(void)std::frexp(extent / 255.0, &ex); // extent / 255 = m * 2^ex, m in [0.5, 1)  =>  2^ex >= extent / 255
+					e = std::max(ex, -126);
+				}
+				while ((double)self.min[a] + 255.0 * std::ldexp(1.0, e) < (double)self.max[a])
+					++e;
+				if (e > 127) {
+					ok = false;
+					break;
+				}
+				dn.exps |= (uint32_t)(e + 127) << (8 * a);
+				const double step = std::ldexp(1.0, e);
+				for (int k = 0; k < n_kids; ++k) {
+					const HostNode &ch = hs.nodes[kids[k]];
+					long lo = (long)std::floor(((double)ch.min[a] - (double)self.min[a]) / step);
+					long hi = (long)std::ceil(((double)ch.max[a] - (double)self.min[a]) / step);
+					lo = std::min(std::max(lo, 0l), 255l);
+					hi = std::min(std::max(hi, 0l), 255l);
+					while (lo > 0 && (double)self.min[a] + (double)lo * step > (double)ch.min[a])
+						--lo;
+					while (hi < 255 && (double)self.min[a] + (double)hi * step < (double)ch.max[a])
+						++hi;
+					if ((double)self.min[a] + (double)lo * step > (double)ch.min[a] || (double)self.min[a] + (double)hi * step < (double)ch.max[a])
+						ok = false; // cannot happen (the child lies inside `self`); never ship a box that does not contain
+					dn.qlo[a] |= (uint32_t)lo << (8 * k);
+					dn.qhi[a] |= (uint32_t)hi << (8 * k);
+				}
+				for (int k = n_kids; k < 4; ++k) // absent children: an inverted interval (and child == kRefNone)
+					dn.qlo[a] |= 255u << (8 * k);
+			}
+			for (int k = 0; k < 4 && ok; ++k) {
 				if (k >= n_kids) {
 					dn.child[k] = kRefNone;
 					continue;
 				}
 				const HostNode &ch = hs.nodes[kids[k]];
-				float e = 0.0f;
-				for (int a = 0; a < 3; ++a) {
-					dn.lo[a][k] = ch.min[a];
-					dn.hi[a][k] = ch.max[a];
-				}
-				e = (ch.max[0] - ch.min[0]) + (ch.max[1] - ch.min[1]) + (ch.max[2] - ch.min[2]); // box_extent_l1's own order
-				dn.ext[k] = e;
 				if (ch.child[0] >= 0) {
 					const uint32_t w = (uint32_t)hs.dev_nodes4.size();
 					hs.dev_nodes4.emplace_back();
@@ -712,11 +747,19 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			}
 			hs.dev_nodes4[it.wide] = dn;
 		}
-		if (wide_stack > 96) { // would not fit the per-lane LDS stack: keep the two-child tree only
+		if (!ok || wide_stack > 96) { // (the stack would not fit the per-lane LDS column): keep the two-child tree only
 			hs.dev_nodes4.clear();
 			hs.root4_ref = hs.root_ref;
 		} else {
 			hs.stack_depth = std::max(hs.stack_depth, wide_stack);
+			// exact boxes of the leaves, by first slot
+			hs.leaf_box.assign(n, DevLeafBox{});
+			for (const HostNode &hn : hs.nodes)
+				if (hn.child[0] < 0) {
+					DevLeafBox &b = hs.leaf_box[hn.primitive_offset];
+					std::memcpy(b.lo, hn.min, 12);
+					std::memcpy(b.hi, hn.max, 12);
+				}
 		}
 	}
 	if (hs.stack_depth > 96) {

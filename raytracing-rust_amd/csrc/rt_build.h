@@ -24,7 +24,8 @@ struct HostScene {
 	std::vector<uint64_t> lights;          // Bvh.lights (slots)
 	// device images
 	std::vector<DevNode> dev_nodes;
-	std::vector<DevNode4> dev_nodes4; // wide tree (empty: not built)
+	std::vector<DevNodeQ4> dev_nodes4; // wide tree (empty: not built)
+	std::vector<DevLeafBox> leaf_box;  // exact leaf boxes by first slot (only with the wide tree)
 	uint32_t root4_ref = 0;
 	std::vector<DevPrim> dev_prims;
 	std::vector<DevShade> dev_shade;

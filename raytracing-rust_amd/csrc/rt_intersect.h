@@ -384,46 +384,77 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uin
 // ---- the wide walk ----
 // WHY ANOTHER TREE RETURNS THE SAME HITS.  The reference tests a leaf's primitives iff the leaf's box and every
 // ancestor's box pass AABB::does_int (mod.rs:199-224).  A node's box is the exact union of its primitives' boxes
-// (mod.rs:105-108), so an ancestor's box contains the leaf's box exactly, and for a REGULAR ray -- every component of
-// origin and 1/direction finite, which makes every (bound - origin) * inverse in the slab test a non-NaN value -- the
-// slab test is monotone in the bounds: each IEEE operation in it is monotone, and on a box that is hit every axis has
-// near = t1 and far = t2 * widen, so a box containing a hit box has tmin no larger and tmax no smaller and is hit too.
-// Hence for regular rays "leaf and all its ancestors hit" == "the leaf's own box is hit": the reference's candidate
-// leaves are exactly the leaves whose own box passes does_int, whatever hierarchy leads to them.  The wide tree keeps
-// the reference's leaves and boxes and only regroups them (four children per 128-byte node), and the walk tests every
-// child box with the reference's predicate, so it reaches exactly those leaves; the winner among their primitives is
-// chosen by the same (t, BFS rank) rule.  Irregular rays (a zero direction component gives an infinite inverse, and
-// 0 * inf = NaN is IGNORED by Rust's min/max, which breaks monotonicity for flat boxes) take the two-child walk, which
-// tests every ancestor as the reference does.  Scenes with non-finite bounds get no wide tree at all.
+// (mod.rs:105-108), so an ancestor's box contains the leaf's box exactly, and for a REGULAR ray -- origin and
+// 1/direction finite and tame, which makes every (bound - origin) * inverse in the slab test a finite, non-NaN value --
+// the slab test is monotone in the bounds: each IEEE operation in it is monotone, and on a box that is hit every axis
+// has near = t1 and far = t2 * widen, so a box containing a hit box has tmin no larger and tmax no smaller and is hit
+// too.  Hence for regular rays "leaf and all its ancestors hit" == "the leaf's OWN box is hit": the reference's
+// candidate leaves are exactly the leaves whose own box passes does_int, whatever hierarchy leads to them.
+// The wide tree (rt_types.h DevNodeQ4) keeps the reference's leaves, regroups the inner nodes four to a 64-byte record
+// and stores CONSERVATIVE child boxes (8-bit grid, rounded outward).  Its walk therefore
+//   1. reaches every leaf whose exact box the ray hits: a stored box contains the leaf's exact box as a set, and the
+//      inner test below is padded by more than the rounding of both tests together (derivation at kWidePad);
+//   2. tests a reached leaf's EXACT box (DevScene::leaf_box) with the reference's own predicate before touching its
+//      primitives, so the primitives tested are exactly the reference's; the winner is chosen by the same (t, BFS rank)
+//      rule.
+// Irregular rays (a zero direction component gives an infinite inverse, and 0 * inf = NaN is IGNORED by Rust's min/max,
+// which breaks monotonicity for flat boxes; huge components could overflow the padded test) take the two-child walk,
+// which tests every ancestor as the reference does.  Scenes with non-finite or huge bounds get no wide tree at all.
 __device__ __forceinline__ bool ray_is_regular(const Ray &r)
 {
-	// finite - finite and finite * 0 stay finite; any NaN or inf operand makes the sum NaN or inf
-	const float probe = (r.o.x + r.o.y + r.o.z) * 0.0f + (fabsf(r.inv.x) + fabsf(r.inv.y) + fabsf(r.inv.z));
-	return probe < INFINITY; // false for NaN too
+	const float mi = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
+	const float mo = fmaxf(fmaxf(fabsf(r.o.x), fabsf(r.o.y)), fabsf(r.o.z));
+	// 2^60: with bounds <= 2^60 (host check) every product in the walk stays far below FLT_MAX.  NaN anywhere -> false
+	// (fmaxf drops a NaN operand, so test the components' sum for NaN as well)
+	const float nan_probe = (r.inv.x + r.inv.y + r.inv.z) + (r.o.x + r.o.y + r.o.z);
+	return mi <= 0x1p60f && mo <= 0x1p60f && nan_probe == nan_probe;
 }
 
-// One step of the wide descent: fetch the 128-byte node, test its (up to) four child boxes with the reference's
-// predicate, prune, go to the nearest surviving child and push the others farthest first.
+// Padding of the inner-node test, relative to M = max|b| + 255 max|a| (the node's distance and extent in ray
+// parameter units; t = q * a + b with a = step / direction, b = (origin - ray origin) / direction per axis).
+//   * this test: b carries two roundings, the fma one: |t_computed - t| <= 2^-23 |b| + 2^-24 |t| <= 2.4e-7 M;
+//   * the reference's test on a box inside this one: tmax is inflated by (1 + 2 gamma(3)) and three roundings,
+//     tmin deflated by two roundings: a box it accepts has tfar - tnear >= -1.1e-6 M in exact arithmetic and tfar > 0.
+// So an accepted descendant implies tfar_computed - tnear_computed >= -1.6e-6 M and tfar_computed >= -2.4e-7 M here;
+// the pad is 1e-5 M on both.  (A pad that is too large only costs visits; too small would lose hits.)
+constexpr float kWidePad = 1.0e-5f;
+
+// One step of the wide descent: fetch the 64-byte node (four dwordx4), test its (up to) four child boxes
+// conservatively, prune, go to the nearest surviving child and push the others farthest first.
 template <bool PRUNE>
 __device__ __forceinline__ uint32_t descend4(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid, float t_limit)
 {
-	const float4 *q = reinterpret_cast<const float4 *>(&S.nodes4[node]);
-	const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-	const float4 refs = q[6], ext = q[7];
-	const float lo[4][3] = {{lox.x, loy.x, loz.x}, {lox.y, loy.y, loz.y}, {lox.z, loy.z, loz.z}, {lox.w, loy.w, loz.w}};
-	const float hi[4][3] = {{hix.x, hiy.x, hiz.x}, {hix.y, hiy.y, hiz.y}, {hix.z, hiy.z, hiz.z}, {hix.w, hiy.w, hiz.w}};
-	const uint32_t ref[4] = {__float_as_uint(refs.x), __float_as_uint(refs.y), __float_as_uint(refs.z), __float_as_uint(refs.w)};
-	const float ex[4] = {ext.x, ext.y, ext.z, ext.w};
-	// sort key: entry distance clamped to >= 0 as ordered bits, child slot in the two low bits (the order is a
-	// heuristic: it decides how soon pruning bites, never what is found); 0xFFFFFFFF = not to be visited
-	uint32_t key[4];
+	const uint4 *q = reinterpret_cast<const uint4 *>(&S.nodes4[node]);
+	const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	const float sx = __uint_as_float((q0.w & 0xFFu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xFFu) << 23),
+	            sz = __uint_as_float(((q0.w >> 16) & 0xFFu) << 23);
+	const float ax = sx * r.inv.x, ay = sy * r.inv.y, az = sz * r.inv.z; // exact: the steps are powers of two
+	const float bx = (__uint_as_float(q0.x) - r.o.x) * r.inv.x, by = (__uint_as_float(q0.y) - r.o.y) * r.inv.y,
+	            bz = (__uint_as_float(q0.z) - r.o.z) * r.inv.z;
+	// grid coordinates of the near and far planes per axis, by the sign of the direction; the four children's bytes
+	// ride in one dword, so one select serves all four
+	const bool negx = r.inv.x < 0.0f, negy = r.inv.y < 0.0f, negz = r.inv.z < 0.0f;
+	const uint32_t nx = negx ? q1.w : q1.x, fx = negx ? q1.x : q1.w;
+	const uint32_t ny = negy ? q2.x : q1.y, fy = negy ? q1.y : q2.x;
+	const uint32_t nz = negz ? q2.y : q1.z, fz = negz ? q1.z : q2.y;
+	const float big = fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz)) + 255.0f * fmaxf(fmaxf(fabsf(ax), fabsf(ay)), fabsf(az));
+	const float pad = kWidePad * big;
+	// prune: nothing inside a child is nearer than te = max(tnear - pad, 0); skip it when te exceeds the limit by the
+	// slack of the two-child walk (kPruneSlack, with the node's whole extent standing in for the child's)
+	const float ext = 255.0f * (sx + sy + sz);
+	const float cut = (PRUNE && limit_valid) ? t_limit + kPruneSlack * (fabsf(t_limit) + ext) : INFINITY;
+	const uint32_t ref[4] = {q2.z, q2.w, q3.x, q3.y};
+	uint32_t key[4]; // entry distance as ordered bits with the child slot in the two low bits; 0xFFFFFFFF = do not visit
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
-		float t;
-		bool h = ref[c] != kRefNone && aabb_does_int(lo[c], hi[c], r, t);
-		if (PRUNE && limit_valid && h && t - kPruneSlack * (fabsf(t) + fabsf(t_limit) + ex[c]) > t_limit)
-			h = false;
-		key[c] = h ? ((__float_as_uint(fmax_(t, 0.0f)) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+		const int sh = 8 * c;
+		const float tn = fmaxf(fmaxf(fmaf((float)((nx >> sh) & 0xFFu), ax, bx), fmaf((float)((ny >> sh) & 0xFFu), ay, by)),
+		                       fmaf((float)((nz >> sh) & 0xFFu), az, bz));
+		const float tf = fminf(fminf(fmaf((float)((fx >> sh) & 0xFFu), ax, bx), fmaf((float)((fy >> sh) & 0xFFu), ay, by)),
+		                       fmaf((float)((fz >> sh) & 0xFFu), az, bz));
+		const float te = fmaxf(tn - pad, 0.0f);
+		const bool h = ref[c] != kRefNone && (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut);
+		key[c] = h ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
 	}
 #define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
 	RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
@@ -439,6 +470,19 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const Ray &r, ui
 	if (key[2] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[2]); ++sp; }
 	if (key[1] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[1]); ++sp; }
 	return ref_of(key[0]);
+}
+
+// the candidate test of the wide walk: does the ray hit this leaf's EXACT reference box (reference predicate)?
+__device__ __forceinline__ bool leaf_box_hit(const DevScene &S, uint32_t leaf, const Ray &r)
+{
+	uint32_t first = leaf & kLeafSlotMask;
+	if (((leaf >> 26) & 31u) == 0u)
+		first = S.big_leaves[first].x;
+	const float4 *q = reinterpret_cast<const float4 *>(&S.leaf_box[first]);
+	const float4 a = q[0], b = q[1];
+	const float lo[3] = {a.x, a.y, a.z}, hi[3] = {b.x, b.y, b.z};
+	float t;
+	return aabb_does_int(lo, hi, r, t);
 }
 
 // The root test of Bvh::get_intersection_candidates (mod.rs:203-210).  It decides something only when the
@@ -530,7 +574,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 			            : descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
-		closest_in_leaf<F>(S, r, node, best_t, best_prim);
+		if (!wide || leaf_box_hit(S, node, r))
+			closest_in_leaf<F>(S, r, node, best_t, best_prim);
 		if (sp == 0)
 			break;
 		--sp;
@@ -568,7 +613,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 			node = wide ? descend4<PRUNE>(S, r, node, stk, sp, limited, t_limit) : descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
-		if (any_in_leaf<F>(S, r, node, t_limit, skip))
+		if ((!wide || leaf_box_hit(S, node, r)) && any_in_leaf<F>(S, r, node, t_limit, skip))
 			return true;
 		if (sp == 0)
 			break;

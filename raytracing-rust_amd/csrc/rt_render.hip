@@ -340,6 +340,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	auto do_leaf = [&]() {
 		uint32_t first, count;
 		leaf_range(S, node, first, count);
+		// the walk got here through conservative boxes: the leaf is a candidate iff its exact box passes the
+		// reference's test (rt_intersect.h, the wide walk)
+		if (!leaf_box_hit(S, node, ray))
+			count = 0u;
 		bool occluded = false;
 		for (uint32_t slot = first; slot < first + count; ++slot) {
 			if (any_hit && slot == PL.skip)

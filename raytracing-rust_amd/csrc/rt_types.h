@@ -46,20 +46,30 @@ struct alignas(64) DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 
-// Wide node: up to four children of a collapsed subtree of the reference tree, one 128-byte record = one L2 line
-// (L1->L2 requests, L2 misses and fabric requests are all per 128-byte line on this chip:
-// profiles/r02_fabric_counter_calibration.txt -- a 64-byte two-child node costs the same line and wastes half of
-// it).  Bounds are the children's EXACT reference boxes, stored per axis for the four children (SoA), so a step is
-// eight dwordx4 loads of one line.  `ext` = (max-min) summed over the axes per child (what the prune test needs),
-// absent children have child == kRefNone.  Why walking this tree returns the reference's hits: rt_intersect.h.
+// Wide node: up to four children of a collapsed subtree of the reference tree in ONE 64-byte record.  What bounds a
+// walk over a big tree on this chip is the rate at which a CU's texture addresser / L1 serves DIVERGENT 16-byte lane
+// loads (about 0.75 per cycle per CU; profiles/r02c_*): the cost of a walk is the number of 16-byte pieces its lanes
+// fetch, so the node carries as much tree per piece as it can: child boxes are 8-bit offsets on a per-node grid
+// (origin + q * 2^exp per axis), rounded OUTWARD, i.e. conservative supersets of the reference boxes.  Conservative boxes
+// only decide where the walk goes; whether a leaf's primitives are tested is decided by the leaf's EXACT reference
+// box (DevScene::leaf_box) and the reference's own predicate.  Why that returns the reference's hits: rt_intersect.h.
+// Absent children have child == kRefNone.
 constexpr uint32_t kRefNone = 0x7FFFFFFEu;
-struct alignas(128) DevNode4 {
-	float lo[3][4];
-	float hi[3][4];
+struct alignas(64) DevNodeQ4 {
+	float origin[3];     // lower corner of the node's grid
+	uint32_t exps;       // byte k (k = 0..2): biased exponent of axis k's grid step, i.e. step = bits(exp << 23)
+	uint32_t qlo[3];     // qlo[axis]: byte c = child c's lower bound on the grid
+	uint32_t qhi[3];     //            ... upper bound
 	uint32_t child[4];
-	float ext[4];
+	uint32_t pad[2];
 };
-static_assert(sizeof(DevNode4) == 128, "DevNode4 must be one 128-byte line");
+static_assert(sizeof(DevNodeQ4) == 64, "DevNodeQ4 must be one 64-byte record");
+
+// exact reference box of a leaf, indexed by the leaf's FIRST primitive slot (32-byte stride: two dwordx4)
+struct alignas(32) DevLeafBox {
+	float lo[3], pad0;
+	float hi[3], pad1;
+};
 
 enum : uint32_t { kPrimSphere = 0, kPrimTriangle = 1, kPrimMeshTriangle = 2 };
 
@@ -133,7 +143,8 @@ struct DevScene {
 	uint32_t blob_bytes;
 	uint32_t off_nodes, off_prims, off_shade, off_rank, off_materials, off_textures, off_lights, off_big_leaves;
 	uint32_t stack_depth;      // traversal stack entries per lane (enough for the two-child AND the wide walk)
-	const DevNode4 *nodes4;    // wide tree (null: none was built, e.g. non-finite bounds)
+	const DevNodeQ4 *nodes4;   // wide tree (null: none was built, e.g. non-finite bounds)
+	const DevLeafBox *leaf_box; // exact leaf boxes for the wide walk, by first primitive slot
 	uint32_t root4_ref;        // child-style reference to its root
 	uint32_t n_nodes4;
 	uint32_t narrow_only;      // RT_TUNE_WALK = 1: every ray takes the two-child walk (tests, A/B measurements)
