@@ -268,8 +268,11 @@ int rt_scene_set_traversal(rt_scene *scene, int mode);
  *                         per-lane state machine is voted; implies the pruned walk)
  *   RT_TUNE_WALK          0 automatic: pruned walks use the wide (four-child, 128-byte-node) regrouping of the
  *                         reference tree for regular rays and the two-child tree for the rest; 1: the two-child
- *                         tree for every ray */
-typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3, RT_TUNE_WALK = 4 } rt_tuning_key;
+ *                         tree for every ray
+ *   RT_TUNE_STACK_CAP     0 automatic; n: keep at most n traversal-stack entries per lane in LDS, the rest of the
+ *                         tree's worst case in the global overflow area (exercises that path on small trees) */
+typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3, RT_TUNE_WALK = 4,
+                             RT_TUNE_STACK_CAP = 5 } rt_tuning_key;
 int rt_scene_set_tuning(rt_scene *scene, int key, int value);
 
 /* ---- Sampler::sample_image  samplers/random_sampler.rs:10-99 ----

@@ -20,12 +20,13 @@
 #include "rt_types.h"
 
 namespace rt {
-size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block);
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block, uint32_t stack_cap);
+uint32_t render_waves_per_simd(int feature_set, bool fine);
 uint32_t render_block_threads(int feature_set, bool fine);
 hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter);
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
@@ -93,6 +94,9 @@ struct rt_scene {
 	hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
 	size_t max_lds = 65536;
 	rt_launch_info last_launch{};
+	uint32_t stack_cap_override = 0; // RT_TUNE_STACK_CAP
+	uint32_t *d_stack_ovf = nullptr; // traversal-stack overflow area (deep trees under the fine schedule), grown on demand
+	size_t stack_ovf_words = 0;
 	uint8_t *d_rgb8 = nullptr; // rt_render_rgb8: the quantised frame
 	size_t d_rgb8_bytes = 0;
 };
@@ -162,6 +166,8 @@ void rt_scene_destroy(rt_scene *s)
 		(void)hipFree(s->d_partial);
 	if (s->d_rgb8)
 		(void)hipFree(s->d_rgb8);
+	if (s->d_stack_ovf)
+		(void)hipFree(s->d_stack_ovf);
 	for (int b = 0; b < 2; ++b) {
 		if (s->d_prog[b]) (void)hipFree(s->d_prog[b]);
 		if (s->h_prog[b]) (void)hipHostFree(s->h_prog[b]);
@@ -367,6 +373,11 @@ int rt_scene_set_tuning(rt_scene *s, int key, int value)
 		return RT_OK;
 	case RT_TUNE_SCENE_IN_LDS:
 		s->scene_lds_allowed = value != 0;
+		return RT_OK;
+	case RT_TUNE_STACK_CAP:
+		if (value < 0 || value > 96)
+			return fail(RT_ERR_INVALID_ARGUMENT, "stack cap must be 0 (automatic) or 1..96 entries");
+		s->stack_cap_override = (uint32_t)value;
 		return RT_OK;
 	case RT_TUNE_WALK:
 		if (value < 0 || value > 1)
@@ -608,13 +619,28 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	const bool scene_lds = !fine && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
 	P.scene_in_lds = scene_lds ? 1u : 0u;
 	bool sky_lds = false;
-	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, render_block_threads(s->feature_set, fine) / 64u);
+	const uint32_t block_threads = render_block_threads(s->feature_set, fine);
+	// Traversal stacks: one LDS column per lane.  The worst case of a deep tree (three pending siblings per level of
+	// the wide tree) is far above what walks reach, and LDS sized for it would cost resident waves; under the fine
+	// schedule the LDS part is capped at the share a workgroup gets at the occupancy its register budget allows, the
+	// rest of the worst case lives in a global overflow area that is touched only if a walk really gets that deep.
+	uint32_t stack_cap = s->dev.stack_depth;
+	if (fine) {
+		const uint32_t blocks_wanted = std::max(1u, render_waves_per_simd(s->feature_set, true) * 256u / block_threads);
+		const uint32_t fit = (uint32_t)(s->max_lds / blocks_wanted) / ((block_threads / 64u) * 64u * 4u);
+		stack_cap = std::min(stack_cap, std::max(8u, fit));
+	}
+	if (s->stack_cap_override != 0u)
+		stack_cap = std::min(s->dev.stack_depth, s->stack_cap_override);
+	P.stack_cap = stack_cap;
+	P.stack_ovf_depth = s->dev.stack_depth - stack_cap;
+	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, block_threads / 64u, stack_cap);
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
 	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, render_block_threads(s->feature_set, fine) / 64u);
+		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, block_threads / 64u, stack_cap);
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
 		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
@@ -670,9 +696,20 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s>", (int)o->render_method, prune ? "true" : "false",
 		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set]);
 	}
+	if (P.stack_ovf_depth != 0u) { // grown on first use only (like the sample_split scratch: not capturable on that call)
+		const size_t need = (size_t)n_blocks * block_threads * P.stack_ovf_depth;
+		if (need > s->stack_ovf_words) {
+			if (s->d_stack_ovf)
+				(void)hipFree(s->d_stack_ovf);
+			s->d_stack_ovf = nullptr;
+			s->stack_ovf_words = 0;
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_stack_ovf), need * sizeof(uint32_t)));
+			s->stack_ovf_words = need;
+		}
+	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
 	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
-	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter));
+	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
 		HIP_TRY(launch_combine(stream, P, s->d_partial, d_out_rgb));

@@ -284,6 +284,36 @@ __device__ __forceinline__ void make_sky_hit(const DevScene &S, Hit &h, uint32_t
 // Per-lane stack in LDS: entry e of lane l lives at stack[e * 64 + l]; `stk` already points at
 // the lane's column, so consecutive lanes hit consecutive banks (conflict-free ds_read/ds_write_b32).
 constexpr int kStackStride = 64;
+// Where a lane's stack lives: the first `cap` entries in its LDS column, the rest (rare: the host sizes `cap` from the
+// occupancy it wants, the worst case of a wide tree is far above what walks reach) in a global overflow area
+// [thread][ovf_depth].  All fields are wave-uniform.  The overflow address is recomputed from the LDS column pointer when
+// needed, so the common path carries no extra per-lane register.
+struct StackMem {
+	uint32_t cap;       // entries per lane in LDS
+	uint32_t ovf_depth; // entries per lane in the overflow area (0: none, cap covers the worst case)
+	uint32_t *ovf;
+	uint32_t *region;   // LDS: start of this workgroup's stack region (wave w's columns start at region + w * cap * 64)
+};
+__device__ __forceinline__ uint32_t *stack_overflow_slot(const StackMem &M, const uint32_t *stk, int sp)
+{
+	const uint32_t idx = (uint32_t)(stk - M.region); // wave * cap * 64 + lane
+	const uint32_t wave = idx / (M.cap * (uint32_t)kStackStride), lane = idx & 63u;
+	const size_t thread = (size_t)blockIdx.x * blockDim.x + wave * 64u + lane;
+	return M.ovf + thread * M.ovf_depth + ((uint32_t)sp - M.cap);
+}
+__device__ __forceinline__ void stack_store(const StackMem &M, uint32_t *stk, int sp, uint32_t v)
+{
+	if (sp < (int)M.cap)
+		stk[sp * kStackStride] = v;
+	else
+		*stack_overflow_slot(M, stk, sp) = v;
+}
+__device__ __forceinline__ uint32_t stack_load(const StackMem &M, const uint32_t *stk, int sp)
+{
+	if (sp < (int)M.cap)
+		return stk[sp * kStackStride];
+	return *stack_overflow_slot(M, stk, sp);
+}
 constexpr uint32_t kRefDone = 0x7FFFFFFFu; // sentinel: traversal finished
 // Slack used by the pruned walk: a child whose entry distance exceeds the current best t by more
 // than this cannot contain a primitive that beats or ties it (the slab test and the intersectors
@@ -332,42 +362,26 @@ __device__ __forceinline__ bool beyond(float t_entry, float t_best, const float 
 // with the reference's predicate, choose where to go next.  limit_valid/t_limit: prune children
 // entered beyond t_limit (PRUNE only).
 template <bool PRUNE>
-__device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid,
-                                            float t_limit
-#ifdef RT_STATS
-                                            , unsigned long long *g_walk_stats = nullptr // diagnostic build: dead-visit counters
-#endif
-)
+__device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp,
+                                            bool limit_valid, float t_limit)
 {
 	const NodeView n = load_node(S, node);
 	float t0, t1;
 	bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 	bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
-#ifdef RT_STATS
-	const bool g0 = h0, g1 = h1;
-#endif
 	if (PRUNE && limit_valid) {
 		if (h0 && beyond(t0, t_limit, n.c0min, n.c0max))
 			h0 = false;
 		if (h1 && beyond(t1, t_limit, n.c1min, n.c1max))
 			h1 = false;
 	}
-#ifdef RT_STATS
-	if (g_walk_stats && !h0 && !h1) {
-		g_walk_stats[0] += 1;             // dead visit: nothing to descend into
-		if (g0 || g1)
-			g_walk_stats[1] += 1;         // ... and at least one child was hit but pruned
-		if ((g0 && !g1 && !h0) || (g1 && !g0 && !h1) || (g0 && g1))
-			g_walk_stats[2] += 1;         // ... every geometrically hit child was pruned
-	}
-#endif
 	if (h0 && h1) {
 		uint32_t near = n.c0, far = n.c1;
 		if (PRUNE && t1 < t0) { // nearer child first, so the farther one can be pruned later
 			near = n.c1;
 			far = n.c0;
 		}
-		stk[sp * kStackStride] = far;
+		stack_store(M, stk, sp, far);
 		++sp;
 		return near;
 	}
@@ -378,7 +392,7 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const Ray &r, uin
 	if (sp == 0)
 		return kRefDone;
 	--sp;
-	return stk[sp * kStackStride];
+	return stack_load(M, stk, sp);
 }
 
 // ---- the wide walk ----
@@ -422,7 +436,8 @@ constexpr float kWidePad = 1.0e-5f;
 // One step of the wide descent: fetch the 64-byte node (four dwordx4), test its (up to) four child boxes
 // conservatively, prune, go to the nearest surviving child and push the others farthest first.
 template <bool PRUNE>
-__device__ __forceinline__ uint32_t descend4(const DevScene &S, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid, float t_limit)
+__device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid,
+                                             float t_limit)
 {
 	const uint4 *q = reinterpret_cast<const uint4 *>(&S.nodes4[node]);
 	const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -464,11 +479,11 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const Ray &r, ui
 		if (sp == 0)
 			return kRefDone;
 		--sp;
-		return stk[sp * kStackStride];
+		return stack_load(M, stk, sp);
 	}
-	if (key[3] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[3]); ++sp; }
-	if (key[2] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[2]); ++sp; }
-	if (key[1] != 0xFFFFFFFFu) { stk[sp * kStackStride] = ref_of(key[1]); ++sp; }
+	if (key[3] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[3])); ++sp; }
+	if (key[2] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[2])); ++sp; }
+	if (key[1] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[1])); ++sp; }
 	return ref_of(key[0]);
 }
 
@@ -546,7 +561,8 @@ __device__ __forceinline__ bool is_two_leaf_tree(const DevScene &S) { return S.n
 
 // Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
 template <class F, bool PRUNE>
-__device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene &SU, const Ray &r, uint32_t *stk, float &best_t, uint32_t &best_prim)
+__device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float &best_t,
+                                              uint32_t &best_prim)
 {
 	best_t = 0.0f;
 	best_prim = kNoPrim;
@@ -570,8 +586,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = wide ? descend4<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t)
-			            : descend<PRUNE>(S, r, node, stk, sp, best_prim != kNoPrim, best_t);
+			node = wide ? descend4<PRUNE>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t)
+			            : descend<PRUNE>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
 		if (!wide || leaf_box_hit(S, node, r))
@@ -579,7 +595,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 		if (sp == 0)
 			break;
 		--sp;
-		node = stk[sp * kStackStride];
+		node = stack_load(M, stk, sp);
 	}
 }
 
@@ -588,7 +604,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 // some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
 // limit" (any t > 0 occludes).
 template <class F, bool PRUNE>
-__device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU, const Ray &r, uint32_t *stk, float t_limit, uint32_t skip)
+__device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float t_limit,
+                                          uint32_t skip)
 {
 	if (root_box_misses(S, r))
 		return false;
@@ -610,7 +627,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = wide ? descend4<PRUNE>(S, r, node, stk, sp, limited, t_limit) : descend<PRUNE>(S, r, node, stk, sp, limited, t_limit);
+			node = wide ? descend4<PRUNE>(S, M, r, node, stk, sp, limited, t_limit) : descend<PRUNE>(S, M, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
 		if ((!wide || leaf_box_hit(S, node, r)) && any_in_leaf<F>(S, r, node, t_limit, skip))
@@ -618,7 +635,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 		if (sp == 0)
 			break;
 		--sp;
-		node = stk[sp * kStackStride];
+		node = stack_load(M, stk, sp);
 	}
 	return false;
 }

@@ -148,7 +148,7 @@ __device__ unsigned long long g_stats[64];
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
 __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
-                                                     uint32_t *__restrict__ work_counter)
+                                                     uint32_t *__restrict__ work_counter, uint32_t *__restrict__ stack_ovf)
 {
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -203,7 +203,12 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 		S.lights = reinterpret_cast<const uint32_t *>(b + S.off_lights);
 		S.big_leaves = reinterpret_cast<const uint2 *>(b + S.off_big_leaves);
 	}
-	uint32_t *stk = lds + sky_words + blob_words + wave * (S.stack_depth * kStackStride) + lane;
+	StackMem SM;
+	SM.cap = P.stack_cap;
+	SM.ovf_depth = P.stack_ovf_depth;
+	SM.ovf = stack_ovf;
+	SM.region = lds + sky_words + blob_words;
+	uint32_t *stk = SM.region + wave * (P.stack_cap * kStackStride) + lane;
 
 	const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
 	const uint64_t sample_begin = ((uint64_t)P.sample_begin_hi << 32) | P.sample_begin_lo;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			st_lane_maxsp = (unsigned long long)sp;
 #endif
 		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
-		node = descend4<PRUNE>(S, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
+		node = descend4<PRUNE>(S, SM, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
 		after_step();
 	
 	};
@@ -383,7 +388,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			node = kRefDone;
 		} else {
 			--sp;
-			node = stk[sp * kStackStride];
+			node = stack_load(SM, stk, sp);
 		}
 		after_step();
 	
@@ -605,10 +610,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	// direction with an exactly zero component).  trace_closest / trace_any pick that tree for such rays themselves.
 	auto do_narrow = [&]() {
 		if (any_hit) {
-			best_prim = trace_any<F, PRUNE>(S, S_global, ray, stk, PL.t_limit, PL.skip) ? 0u : kNoPrim;
+			best_prim = trace_any<F, PRUNE>(S, S_global, SM, ray, stk, PL.t_limit, PL.skip) ? 0u : kNoPrim;
 			ph = PH_SCATTER;
 		} else {
-			trace_closest<F, PRUNE>(S, S_global, ray, stk, best_t, best_prim);
+			trace_closest<F, PRUNE>(S, S_global, SM, ray, stk, best_t, best_prim);
 			ph = PH_SHADE;
 		}
 		node = kRefDone;
@@ -619,13 +624,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	// of rt_intersect.h (closest walk in the TRACE super-phase, shadow walk in the LIGHT super-phase)
 	auto walk_closest_pending = [&]() {
 		if (ph == PH_NODE && !any_hit) {
-			trace_closest<F, PRUNE>(S, S_global, ray, stk, best_t, best_prim);
+			trace_closest<F, PRUNE>(S, S_global, SM, ray, stk, best_t, best_prim);
 			ph = PH_SHADE;
 		}
 	};
 	auto walk_shadow_pending = [&](const LightCtx &L, const Ray &sr) {
 		if (ph == PH_NODE && any_hit) {
-			best_prim = trace_any<F, PRUNE>(S, S_global, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
+			best_prim = trace_any<F, PRUNE>(S, S_global, SM, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
 			ph = PH_SCATTER;
 		}
 	};
@@ -990,6 +995,9 @@ __global__ __launch_bounds__(256) void check_hit_kernel(const DevScene S, const 
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
+	// the whole worst case in LDS: the overflow branch is never taken (its base only has to be some global pointer;
+	// a literal null there sends this compiler's SimplifyCFG into a crash)
+	const StackMem SM = {S.stack_depth, 0u, reinterpret_cast<uint32_t *>(outr), lds};
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
@@ -997,7 +1005,7 @@ __global__ __launch_bounds__(256) void check_hit_kernel(const DevScene S, const 
 	                      v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]));
 	float t;
 	uint32_t prim;
-	trace_closest<F, PRUNE>(S, S, r, stk, t, prim);
+	trace_closest<F, PRUNE>(S, S, SM, r, stk, t, prim);
 	Hit h;
 	uint32_t m;
 	if (prim != kNoPrim) {
@@ -1018,6 +1026,7 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *stk = lds + wave * (S.stack_depth * kStackStride) + lane;
+	const StackMem SM = {S.stack_depth, 0u, reinterpret_cast<uint32_t *>(outr), lds}; // see check_hit_kernel
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
 		return;
@@ -1034,7 +1043,7 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 	bool found = false;
 	float lt;
 	if (prim_t<F>(g, r, lt) && lt > 0.0f) {
-		if (!trace_any<F, PRUNE>(S, S, r, stk, lt, index)) {
+		if (!trace_any<F, PRUNE>(S, S, SM, r, stk, lt, index)) {
 			make_hit<F>(S, index, r, lt, h, m);
 			found = true;
 		}
@@ -1065,7 +1074,17 @@ uint32_t render_block_threads(int feature_set, bool fine)
 	return 256u;
 }
 
-size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block)
+// waves per SIMD the kernel's register budget is declared for (its __launch_bounds__)
+uint32_t render_waves_per_simd(int feature_set, bool fine)
+{
+	if (feature_set == 0)
+		return fine ? (uint32_t)KernelShape<Feat<false, false, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<false, false, false, false>, false>::waves_per_simd;
+	if (feature_set == 1)
+		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::waves_per_simd;
+	return fine ? (uint32_t)KernelShape<FeatFull, true>::waves_per_simd : (uint32_t)KernelShape<FeatFull, false>::waves_per_simd;
+}
+
+size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block, uint32_t stack_cap)
 {
 	size_t words = scene_lds ? S.blob_bytes / 4u : 0u;
 	if (sky_lds) {
@@ -1073,11 +1092,11 @@ size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_
 		words += (n_all + 3u) & ~3u;
 		words += (S.sky.res_y + 1u) * S.sky.guide_k / 4u;
 	}
-	words += (size_t)waves_per_block * S.stack_depth * kStackStride;
+	words += (size_t)waves_per_block * stack_cap * kStackStride;
 	return words * sizeof(uint32_t);
 }
 
-typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams, float *, unsigned long long *, uint32_t *);
+typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams, float *, unsigned long long *, uint32_t *, uint32_t *);
 
 // feature sets the render kernel is instantiated for (rt_api.cpp picks the smallest that covers the scene)
 using FeatSpheres = Feat<false, false, false, false>; // spheres, Lambertian/Emit, Solid/Lerp, sky is the only light (rtweekend1)
@@ -1129,12 +1148,13 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter)
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf)
 {
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
 	if (!fn)
 		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter);
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter,
+	                   stack_ovf);
 	return hipGetLastError();
 }
 

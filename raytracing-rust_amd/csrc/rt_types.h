@@ -171,6 +171,8 @@ struct DevRenderParams {
 	int32_t prune;            // t-pruned traversal (validated equal to the reference's exhaustive one)
 	uint32_t sky_in_lds;      // sky CDF tables are staged in LDS
 	uint32_t scene_in_lds;    // the scene blob is staged in LDS (tiny scenes)
+	uint32_t stack_cap;       // traversal stack entries per lane kept in LDS (rt_intersect.h StackMem)
+	uint32_t stack_ovf_depth; // ... and in the global overflow area (0: the LDS part covers the worst case)
 };
 
 } // namespace rt
