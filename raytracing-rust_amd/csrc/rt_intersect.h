@@ -468,14 +468,33 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 		const float tf = fminf(fminf(fmaf((float)((fx >> sh) & 0xFFu), ax, bx), fmaf((float)((fy >> sh) & 0xFFu), ay, by)),
 		                       fmaf((float)((fz >> sh) & 0xFFu), az, bz));
 		const float te = fmaxf(tn - pad, 0.0f);
-		const bool h = ref[c] != kRefNone && (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut);
+		// `&`, not `&&`: four compares and-ed as lane masks, no branch per child
+		const bool h = (ref[c] != kRefNone) & (tf - tn >= -2.0f * pad) & (tf >= -pad) & (te - kPruneSlack * te <= cut);
 		key[c] = h ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
 	}
 #define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
 	RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
 	auto ref_of = [&](uint32_t k) { const uint32_t c = k & 3u; return c == 0u ? ref[0] : (c == 1u ? ref[1] : (c == 2u ? ref[2] : ref[3])); };
-	if (key[0] == 0xFFFFFFFFu) { // nothing to descend into
+	// one wave-uniform question instead of a capacity check per access: can any lane leave the LDS part of its stack
+	// in this step?  (Almost never: the LDS part is sized well above what walks reach.)
+	if (__builtin_expect(__ballot(sp + 3 > (int)M.cap) == 0ull, 1)) {
+		// branch-free pushes: store unconditionally at the top, advance only for a real entry (a store that is not
+		// kept lands in the slot the next one overwrites; sp + 3 <= cap keeps all three inside the column)
+		stk[sp * kStackStride] = ref_of(key[3]);
+		sp += key[3] != 0xFFFFFFFFu ? 1 : 0;
+		stk[sp * kStackStride] = ref_of(key[2]);
+		sp += key[2] != 0xFFFFFFFFu ? 1 : 0;
+		stk[sp * kStackStride] = ref_of(key[1]);
+		sp += key[1] != 0xFFFFFFFFu ? 1 : 0;
+		if (key[0] != 0xFFFFFFFFu)
+			return ref_of(key[0]);
+		if (sp == 0) // nothing to descend into: back to the nearest pending sibling
+			return kRefDone;
+		--sp;
+		return stk[sp * kStackStride];
+	}
+	if (key[0] == 0xFFFFFFFFu) {
 		if (sp == 0)
 			return kRefDone;
 		--sp;
