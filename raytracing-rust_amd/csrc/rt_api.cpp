@@ -630,7 +630,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		const uint32_t fit = (uint32_t)(s->max_lds / blocks_wanted) / ((block_threads / 64u) * 64u * 4u);
 		stack_cap = std::min(stack_cap, std::max(8u, fit));
 	}
-	if (s->stack_cap_override != 0u)
+	if (fine && s->stack_cap_override != 0u) // (coarse kernels keep the whole stack in LDS and walk without capacity checks)
 		stack_cap = std::min(s->dev.stack_depth, s->stack_cap_override);
 	P.stack_cap = stack_cap;
 	P.stack_ovf_depth = s->dev.stack_depth - stack_cap;

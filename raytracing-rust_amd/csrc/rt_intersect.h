@@ -301,16 +301,17 @@ __device__ __forceinline__ uint32_t *stack_overflow_slot(const StackMem &M, cons
 	const size_t thread = (size_t)blockIdx.x * blockDim.x + wave * 64u + lane;
 	return M.ovf + thread * M.ovf_depth + ((uint32_t)sp - M.cap);
 }
-__device__ __forceinline__ void stack_store(const StackMem &M, uint32_t *stk, int sp, uint32_t v)
+// OVF = false: the caller knows the LDS part covers the worst case (ovf_depth == 0): plain LDS accesses
+template <bool OVF> __device__ __forceinline__ void stack_store(const StackMem &M, uint32_t *stk, int sp, uint32_t v)
 {
-	if (sp < (int)M.cap)
+	if (!OVF || sp < (int)M.cap)
 		stk[sp * kStackStride] = v;
 	else
 		*stack_overflow_slot(M, stk, sp) = v;
 }
-__device__ __forceinline__ uint32_t stack_load(const StackMem &M, const uint32_t *stk, int sp)
+template <bool OVF> __device__ __forceinline__ uint32_t stack_load(const StackMem &M, const uint32_t *stk, int sp)
 {
-	if (sp < (int)M.cap)
+	if (!OVF || sp < (int)M.cap)
 		return stk[sp * kStackStride];
 	return *stack_overflow_slot(M, stk, sp);
 }
@@ -361,7 +362,7 @@ __device__ __forceinline__ bool beyond(float t_entry, float t_best, const float 
 // One step of the inner-node descent shared by both walks: fetch `node`, test both child boxes
 // with the reference's predicate, choose where to go next.  limit_valid/t_limit: prune children
 // entered beyond t_limit (PRUNE only).
-template <bool PRUNE>
+template <bool PRUNE, bool OVF>
 __device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp,
                                             bool limit_valid, float t_limit)
 {
@@ -381,7 +382,7 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M
 			near = n.c1;
 			far = n.c0;
 		}
-		stack_store(M, stk, sp, far);
+		stack_store<OVF>(M, stk, sp, far);
 		++sp;
 		return near;
 	}
@@ -392,7 +393,7 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M
 	if (sp == 0)
 		return kRefDone;
 	--sp;
-	return stack_load(M, stk, sp);
+	return stack_load<OVF>(M, stk, sp);
 }
 
 // ---- the wide walk ----
@@ -435,7 +436,7 @@ constexpr float kWidePad = 1.0e-5f;
 
 // One step of the wide descent: fetch the 64-byte node (four dwordx4), test its (up to) four child boxes
 // conservatively, prune, go to the nearest surviving child and push the others farthest first.
-template <bool PRUNE>
+template <bool PRUNE, bool OVF>
 __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp, bool limit_valid,
                                              float t_limit)
 {
@@ -468,41 +469,22 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 		const float tf = fminf(fminf(fmaf((float)((fx >> sh) & 0xFFu), ax, bx), fmaf((float)((fy >> sh) & 0xFFu), ay, by)),
 		                       fmaf((float)((fz >> sh) & 0xFFu), az, bz));
 		const float te = fmaxf(tn - pad, 0.0f);
-		// `&`, not `&&`: four compares and-ed as lane masks, no branch per child
-		const bool h = (ref[c] != kRefNone) & (tf - tn >= -2.0f * pad) & (tf >= -pad) & (te - kPruneSlack * te <= cut);
+		const bool h = ref[c] != kRefNone && (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut);
 		key[c] = h ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
 	}
 #define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
 	RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
 	auto ref_of = [&](uint32_t k) { const uint32_t c = k & 3u; return c == 0u ? ref[0] : (c == 1u ? ref[1] : (c == 2u ? ref[2] : ref[3])); };
-	// one wave-uniform question instead of a capacity check per access: can any lane leave the LDS part of its stack
-	// in this step?  (Almost never: the LDS part is sized well above what walks reach.)
-	if (__builtin_expect(__ballot(sp + 3 > (int)M.cap) == 0ull, 1)) {
-		// branch-free pushes: store unconditionally at the top, advance only for a real entry (a store that is not
-		// kept lands in the slot the next one overwrites; sp + 3 <= cap keeps all three inside the column)
-		stk[sp * kStackStride] = ref_of(key[3]);
-		sp += key[3] != 0xFFFFFFFFu ? 1 : 0;
-		stk[sp * kStackStride] = ref_of(key[2]);
-		sp += key[2] != 0xFFFFFFFFu ? 1 : 0;
-		stk[sp * kStackStride] = ref_of(key[1]);
-		sp += key[1] != 0xFFFFFFFFu ? 1 : 0;
-		if (key[0] != 0xFFFFFFFFu)
-			return ref_of(key[0]);
-		if (sp == 0) // nothing to descend into: back to the nearest pending sibling
-			return kRefDone;
-		--sp;
-		return stk[sp * kStackStride];
-	}
-	if (key[0] == 0xFFFFFFFFu) {
+	if (key[0] == 0xFFFFFFFFu) { // nothing to descend into: back to the nearest pending sibling
 		if (sp == 0)
 			return kRefDone;
 		--sp;
-		return stack_load(M, stk, sp);
+		return stack_load<OVF>(M, stk, sp);
 	}
-	if (key[3] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[3])); ++sp; }
-	if (key[2] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[2])); ++sp; }
-	if (key[1] != 0xFFFFFFFFu) { stack_store(M, stk, sp, ref_of(key[1])); ++sp; }
+	if (key[3] != 0xFFFFFFFFu) { stack_store<OVF>(M, stk, sp, ref_of(key[3])); ++sp; }
+	if (key[2] != 0xFFFFFFFFu) { stack_store<OVF>(M, stk, sp, ref_of(key[2])); ++sp; }
+	if (key[1] != 0xFFFFFFFFu) { stack_store<OVF>(M, stk, sp, ref_of(key[1])); ++sp; }
 	return ref_of(key[0]);
 }
 
@@ -579,7 +561,7 @@ __device__ __forceinline__ bool any_in_leaf(const DevScene &S, const Ray &r, uin
 __device__ __forceinline__ bool is_two_leaf_tree(const DevScene &S) { return S.n_nodes == 1u && !ref_is_leaf(S.root_ref); }
 
 // Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
-template <class F, bool PRUNE>
+template <class F, bool PRUNE, bool OVF = false>
 __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float &best_t,
                                               uint32_t &best_prim)
 {
@@ -605,8 +587,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = wide ? descend4<PRUNE>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t)
-			            : descend<PRUNE>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t);
+			node = wide ? descend4<PRUNE, OVF>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t)
+			            : descend<PRUNE, OVF>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
 		if (!wide || leaf_box_hit(S, node, r))
@@ -614,7 +596,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 		if (sp == 0)
 			break;
 		--sp;
-		node = stack_load(M, stk, sp);
+		node = stack_load<OVF>(M, stk, sp);
 	}
 }
 
@@ -622,7 +604,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 // returning an index != usize::MAX, mis.rs:104-115) and Bvh::check_hit_index (mod.rs:244-261):
 // some primitive other than `skip` has 0 < t and NOT (t >= t_limit).  t_limit = NaN means "no
 // limit" (any t > 0 occludes).
-template <class F, bool PRUNE>
+template <class F, bool PRUNE, bool OVF = false>
 __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float t_limit,
                                           uint32_t skip)
 {
@@ -646,7 +628,8 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
-			node = wide ? descend4<PRUNE>(S, M, r, node, stk, sp, limited, t_limit) : descend<PRUNE>(S, M, r, node, stk, sp, limited, t_limit);
+			node = wide ? descend4<PRUNE, OVF>(S, M, r, node, stk, sp, limited, t_limit)
+			            : descend<PRUNE, OVF>(S, M, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
 		if ((!wide || leaf_box_hit(S, node, r)) && any_in_leaf<F>(S, r, node, t_limit, skip))
@@ -654,7 +637,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 		if (sp == 0)
 			break;
 		--sp;
-		node = stack_load(M, stk, sp);
+		node = stack_load<OVF>(M, stk, sp);
 	}
 	return false;
 }

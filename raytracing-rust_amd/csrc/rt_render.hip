@@ -71,7 +71,7 @@ constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase
 #endif
 constexpr uint32_t kDrainLanesHeavy = RT_DRAIN_LANES_HEAVY; // ... the same for the long phases (GEN, SHADE, LIGHT, SCATTER)
 #ifndef RT_NODE_STEPS_PER_VOTE
-#define RT_NODE_STEPS_PER_VOTE 8 // wide tree, 1 M triangles: 8 steps 51.7 ms, 16 steps 52.8, 4 steps 52.7, 32 steps 57.4
+#define RT_NODE_STEPS_PER_VOTE 16 // wide tree, 1 M triangles MIS: 8 steps 51.7 ms, 16 steps 52.8, 4 steps 52.7, 32 steps 57.4 (within noise)
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_FULL_WAVES
@@ -336,7 +336,11 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			st_lane_maxsp = (unsigned long long)sp;
 #endif
 		const bool limit_valid = any_hit ? !(PL.t_limit != PL.t_limit) : (best_prim != kNoPrim);
-		node = descend4<PRUNE>(S, SM, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
+		// wave-uniform: trees whose worst case fits the LDS columns (all but the deepest) take the walk without capacity checks
+		if (SM.ovf_depth == 0u)
+			node = descend4<PRUNE, false>(S, SM, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
+		else
+			node = descend4<PRUNE, true>(S, SM, ray, node, stk, sp, limit_valid, any_hit ? PL.t_limit : best_t);
 		after_step();
 	
 	};
@@ -346,9 +350,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 		uint32_t first, count;
 		leaf_range(S, node, first, count);
 		// the walk got here through conservative boxes: the leaf is a candidate iff its exact box passes the
-		// reference's test (rt_intersect.h, the wide walk).  The first primitive is fetched beside the box, not behind
-		// it: one memory round trip per leaf visit instead of two.
-		PrimGeom g = load_prim<F>(S, first);
+		// reference's test (rt_intersect.h, the wide walk)
 		if (!leaf_box_hit(S, node, ray))
 			count = 0u;
 		bool occluded = false;
@@ -358,8 +360,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 #ifdef RT_STATS
 			st_lane_prims += 1;
 #endif
-			if (slot != first)
-				g = load_prim<F>(S, slot);
+			const PrimGeom g = load_prim<F>(S, slot);
 			float t;
 			if (prim_t<F>(g, ray, t) && t > 0.0f) {
 				if (any_hit) {
@@ -391,7 +392,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			node = kRefDone;
 		} else {
 			--sp;
-			node = stack_load(SM, stk, sp);
+			node = SM.ovf_depth == 0u ? stack_load<false>(SM, stk, sp) : stack_load<true>(SM, stk, sp);
 		}
 		after_step();
 	
@@ -613,10 +614,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	// direction with an exactly zero component).  trace_closest / trace_any pick that tree for such rays themselves.
 	auto do_narrow = [&]() {
 		if (any_hit) {
-			best_prim = trace_any<F, PRUNE>(S, S_global, SM, ray, stk, PL.t_limit, PL.skip) ? 0u : kNoPrim;
+			best_prim = trace_any<F, PRUNE, true>(S, S_global, SM, ray, stk, PL.t_limit, PL.skip) ? 0u : kNoPrim;
 			ph = PH_SCATTER;
 		} else {
-			trace_closest<F, PRUNE>(S, S_global, SM, ray, stk, best_t, best_prim);
+			trace_closest<F, PRUNE, true>(S, S_global, SM, ray, stk, best_t, best_prim);
 			ph = PH_SHADE;
 		}
 		node = kRefDone;
