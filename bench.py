@@ -185,15 +185,21 @@ def walk_stats_child(name):
     scene_desc, camera_params = load_workload(pkg, name)
     g = hb.HipScene(scene_desc, device=0)
     cam = hb.camera_new(**camera_params)
-    o = workload_opts(pkg.abi, name, 2)
+    spp = 2 if "triangles" in WORKLOADS[name] else 16
+    o = workload_opts(pkg.abi, name, spp)
     o.output_layout = pkg.abi.RT_LAYOUT_SHARD
     out = (C.c_ulonglong * 64)()
     hb.lib().rt_debug_stats(out, 1)
     g.render(cam, o)
     hb.lib().rt_debug_stats(out, 1)
-    n = (o.width * o.height // o.shard_count) * 2
-    print(json.dumps({"node_steps_per_sample": out[20] / n, "primitive_tests_per_sample": out[21] / n, "max_stack": int(out[22]),
-                      "counted_on": f"{o.width}x{o.height} shard {o.shard_index}/{o.shard_count} x 2 spp"}), flush=True)
+    n = (o.width * o.height // o.shard_count) * spp
+    res = {"counted_on": f"{o.width}x{o.height} shard {o.shard_index}/{o.shard_count} x {spp} spp"}
+    if out[20]:  # fine schedule (big trees): what the pruned walk did
+        res.update({"node_steps_per_sample": out[20] / n, "primitive_tests_per_sample": out[21] / n, "max_stack": int(out[22])})
+    if out[0]:   # coarse schedule: lanes taking part in the two voted super-phases (live paths per wave iteration)
+        res.update({"primary_phase_lanes": out[1] / out[0], "bounce_phase_lanes": out[3] / max(1, out[2]),
+                    "primary_iterations_per_64_samples": out[0] * 64 / n, "bounce_iterations_per_64_samples": out[2] * 64 / n})
+    print(json.dumps(res), flush=True)
 
 
 def walk_stats(name):
@@ -389,9 +395,14 @@ def main():
                          "note": "every node step is a dependent, effectively random 64-byte fetch; peak = measured dependent-random-fetch "
                                  "rate of an L2-resident set (115 G/s), 57 G/s beyond L2 (profiles/r01d_random_fetch_microbench.txt)"})
         ws = None
-        if "triangles" in w and world == 1 and not args.no_walk_stats:
+        if world == 1 and not args.no_walk_stats:
             ws = walk_stats(name)
-        if ws:
+        if ws and "primary_phase_lanes" in ws:
+            # NS1: how full the waves are at the level cross-lane compaction could fix (paths that wait for the other
+            # super-phase).  The VALU lane utilisation above is lower because lanes also idle INSIDE a phase (branches of
+            # the shading code), which moving path state between lanes cannot touch.
+            roof["phase_participation"] = dict(ws, note="lanes of 64 holding a path that takes part in the voted super-phase, -DRT_STATS build, untimed pass")
+        if ws and "node_steps_per_sample" in ws:
             wb = ws["node_steps_per_sample"] * 64 + ws["primitive_tests_per_sample"] * 48
             roof["pruned_walk"] = dict(ws, bytes_per_sample=wb, requested_GBps=wb * launch_samples / k_s / 1e9,
                                        note="counted by the -DRT_STATS build on an untimed pass: 64 B per node step + 48 B per primitive test")
