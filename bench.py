@@ -185,7 +185,7 @@ def walk_stats_child(name):
     scene_desc, camera_params = load_workload(pkg, name)
     g = hb.HipScene(scene_desc, device=0)
     cam = hb.camera_new(**camera_params)
-    spp = 2 if "triangles" in WORKLOADS[name] else 16
+    spp = 2 if "triangles" in WORKLOADS[name] else 64
     o = workload_opts(pkg.abi, name, spp)
     o.output_layout = pkg.abi.RT_LAYOUT_SHARD
     out = (C.c_ulonglong * 64)()
@@ -287,6 +287,8 @@ def main():
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # the latter: rehearse the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")  # only missing in the one-rank rehearsal (RT_BENCH_FORCE_DIST)
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = importlib.import_module("raytracing-rust_amd")
@@ -413,10 +415,13 @@ def main():
             roof.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": min(achieved / HBM_PEAK_GBS, 1.0) if achieved else None,
                          "achievable_peak": HBM_ACHIEVABLE_GBS,
-                         "fabric_GBps_from_pmc": measured, "l2_hit_rate": counters.get("l2_hit_rate"),
+                         "fabric_GBps_from_pmc": measured, "fabric_frac_of_peak": measured / HBM_PEAK_GBS if measured else None,
+                         "fabric_frac_of_achievable": measured / HBM_ACHIEVABLE_GBS if measured else None,
+                         "l2_hit_rate": counters.get("l2_hit_rate"),
                          "lane_utilisation": counters.get("valu_lane_utilisation"),
                          "note": "achieved = bytes the pruned walk REQUESTS (64 B/node step + 48 B/primitive test, counted live) / kernel time; "
-                                 "L1/L2 absorb part of it: fabric_GBps_from_pmc is what left L2 (Infinity Cache + HBM) in the committed profile"})
+                                 "fabric_GBps_from_pmc = what crossed the fabric (Infinity Cache + HBM, 128-byte lines) in the committed profile "
+                                 "of this build: above the requested bytes because a 64-byte node uses half of the line it arrives in"})
         if w["bytes"]:
             roof["survey_8d_algorithmic"] = {"bytes_per_sample": w["bytes"], "requested_GBps": w["bytes"] * launch_samples / k_s / 1e9,
                                              "note": "requested bytes under REFERENCE traversal semantics (no pruning, oracle-counted); not HBM bytes, not a roofline fraction"}
