@@ -253,6 +253,18 @@ int rt_scene_get_nodes(const rt_scene *scene, rt_bvh_node *out, uint64_t capacit
  * (the permutation sort_by_indices applies, acceleration/mod.rs:79-82) */
 int rt_scene_get_primitive_order(const rt_scene *scene, uint64_t *out, uint64_t capacity);
 int rt_scene_get_lights(const rt_scene *scene, uint64_t *out, uint64_t capacity); /* Bvh.lights :84-88 */
+/* The wide tree (four-child quantised regrouping of the reference tree that pruned walks of regular rays descend;
+ * see rt_types.h DevNodeQ4 and rt_intersect.h) for inspection by tests: n_wide_nodes 64-byte records
+ * { float origin[3]; uint32 exps; uint32 qlo[3]; uint32 qhi[3]; uint32 child[4]; uint32 pad[2]; },
+ * child: bit 31 set = leaf (bits 26-30 primitive count or 0 = big leaf, bits 0-25 first slot), 0x7FFFFFFE = absent,
+ * otherwise a wide-node index; root_ref in the same encoding; stack_depth = traversal stack entries the scene needs.
+ * n_wide_nodes = 0: no wide tree (non-finite or huge bounds, or a single leaf). */
+int rt_scene_wide_info(const rt_scene *scene, uint64_t *n_wide_nodes, uint32_t *root_ref, uint32_t *stack_depth);
+int rt_scene_get_wide_nodes(const rt_scene *scene, void *out, uint64_t capacity_nodes);
+/* exact leaf boxes of the wide walk, one { float lo[3], pad, hi[3], pad } per primitive slot (meaningful at the first
+ * slot of every leaf) */
+int rt_scene_get_leaf_boxes(const rt_scene *scene, float *out, uint64_t capacity_slots);
+
 /* How the BVH is walked: -1 automatic (default), 0 exhaustive = every AABB-hit node and every
  * primitive of every hit leaf, the reference's own amount of work (acceleration/mod.rs:199-224,
  * 270-293), 1 = near-first with t-pruning.  All modes return the same hits. */

@@ -233,6 +233,9 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_nodes",
     "rt_scene_get_primitive_order",
     "rt_scene_get_lights",
+    "rt_scene_wide_info",
+    "rt_scene_get_wide_nodes",
+    "rt_scene_get_leaf_boxes",
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",
     "rt_render",

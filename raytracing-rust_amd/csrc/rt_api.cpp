@@ -420,6 +420,29 @@ int rt_scene_get_primitive_order(const rt_scene *s, uint64_t *out, uint64_t capa
 	std::memcpy(out, s->host.primitive_order.data(), s->host.primitive_order.size() * sizeof(uint64_t));
 	return RT_OK;
 }
+int rt_scene_wide_info(const rt_scene *s, uint64_t *n_wide_nodes, uint32_t *root_ref, uint32_t *stack_depth)
+{
+	if (!s)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null scene");
+	if (n_wide_nodes) *n_wide_nodes = s->host.dev_nodes4.size();
+	if (root_ref) *root_ref = s->host.root4_ref;
+	if (stack_depth) *stack_depth = s->host.stack_depth;
+	return RT_OK;
+}
+int rt_scene_get_wide_nodes(const rt_scene *s, void *out, uint64_t capacity_nodes)
+{
+	if (!s || !out || capacity_nodes < s->host.dev_nodes4.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.dev_nodes4.data(), s->host.dev_nodes4.size() * sizeof(DevNodeQ4));
+	return RT_OK;
+}
+int rt_scene_get_leaf_boxes(const rt_scene *s, float *out, uint64_t capacity_slots)
+{
+	if (!s || !out || capacity_slots < s->host.leaf_box.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.leaf_box.data(), s->host.leaf_box.size() * sizeof(DevLeafBox));
+	return RT_OK;
+}
 int rt_scene_get_lights(const rt_scene *s, uint64_t *out, uint64_t capacity)
 {
 	if (!s || !out || capacity < s->host.lights.size())

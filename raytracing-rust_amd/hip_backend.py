@@ -79,6 +79,10 @@ NODE_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("children", "<i8",
                        ("number_primitives", "<u8")])
 
 
+WIDE_NODE_DTYPE = np.dtype([("origin", "<f4", 3), ("exps", "<u4"), ("qlo", "<u4", 3), ("qhi", "<u4", 3), ("child", "<u4", 4),
+                            ("pad", "<u4", 2)])
+
+
 def _pack_rays(origins, directions):
     o = np.asarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.asarray(directions, dtype=np.float32).reshape(-1, 3)
@@ -129,6 +133,17 @@ class HipScene:
         out = np.zeros(max(1, n), dtype=np.uint64)
         _check(lib().rt_scene_get_lights(self._h, _p(out, C.c_uint64), C.c_uint64(n)))
         return out[:n]
+
+    def wide_tree(self):
+        """(wide nodes as a structured array, root ref, stack depth, leaf boxes [n_slots, 8]) -- what pruned walks descend"""
+        n, root, depth = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_scene_wide_info(self._h, C.byref(n), C.byref(root), C.byref(depth)))
+        nodes = np.zeros(max(1, n.value), dtype=WIDE_NODE_DTYPE)
+        boxes = np.zeros((max(1, self.counts()[1]), 8), dtype=np.float32)
+        if n.value:
+            _check(lib().rt_scene_get_wide_nodes(self._h, nodes.ctypes.data_as(C.c_void_p), C.c_uint64(n.value)))
+            _check(lib().rt_scene_get_leaf_boxes(self._h, _p(boxes, C.c_float), C.c_uint64(boxes.shape[0])))
+        return nodes[:n.value], root.value, depth.value, boxes
 
     def set_traversal(self, mode):
         """-1 auto, 0 exhaustive (reference amount of work), 1 pruned."""

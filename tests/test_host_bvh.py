@@ -118,3 +118,100 @@ def test_malformed_descriptors_are_refused_not_crashed(hb):
             assert rc == abi.RT_ERR_INVALID_ARGUMENT, (kind, rc, hb.lib().rt_last_error())
             n_refused += 1
     assert n_refused > 150 and n_accepted > 10
+
+
+# ---- the wide tree (DevNodeQ4, csrc/rt_build.cpp): an independent check in float64 of what the exactness argument of
+# rt_intersect.h ("the wide walk") needs from the host: every reference leaf reachable exactly once, every stored child
+# box a SUPERSET of the reference box of everything below it, exact leaf boxes, and a stack bound that covers every path ----
+LEAF = 0x80000000
+NONE = 0x7FFFFFFE
+
+
+def _check_wide_tree(g):
+    ref_nodes = g.nodes()
+    wide, root, depth, leaf_boxes = g.wide_tree()
+    leaves = {int(n["primitive_offset"]): n for n in ref_nodes if n["children"][0] < 0}
+    # leaves of more than 31 primitives are referenced through a table filled in node order (rt_build.cpp)
+    big_leaves = [n for n in ref_nodes if n["children"][0] < 0 and n["number_primitives"] > 31]
+    if len(wide) == 0:
+        return 0
+    seen = []
+
+    def grid_box(node, k):
+        lo, hi = np.zeros(3), np.zeros(3)
+        for a in range(3):
+            step = 2.0 ** (int((node["exps"] >> (8 * a)) & 0xFF) - 127)
+            lo[a] = float(node["origin"][a]) + float((int(node["qlo"][a]) >> (8 * k)) & 0xFF) * step
+            hi[a] = float(node["origin"][a]) + float((int(node["qhi"][a]) >> (8 * k)) & 0xFF) * step
+        return lo, hi
+
+    def below(ref, stack_need):
+        """exact bounds (float64) of everything below `ref`; checks containment on the way"""
+        if ref & LEAF:
+            count, first = (ref >> 26) & 31, ref & 0x03FFFFFF
+            if count == 0:
+                n = big_leaves[first]
+                first = int(n["primitive_offset"])
+            else:
+                n = leaves[first]
+                assert int(n["number_primitives"]) == count
+            seen.append(first)
+            # the exact leaf box the walk tests is the reference node's box, bit for bit
+            assert leaf_boxes[first, 0:3].tobytes() == n["min"].tobytes() and leaf_boxes[first, 4:7].tobytes() == n["max"].tobytes()
+            return n["min"].astype(np.float64), n["max"].astype(np.float64)
+        node = wide[ref]
+        kids = [int(c) for c in node["child"] if int(c) != NONE]
+        assert 2 <= len(kids) <= 4 and all(int(c) == NONE for c in node["child"][len(kids):])
+        need = stack_need + len(kids) - 1
+        assert need + 1 <= depth, (need, depth)
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for k, c in enumerate(kids):
+            b = below(c, need)
+            lo, hi = grid_box(node, k)
+            assert (lo <= b[0]).all() and (hi >= b[1]).all(), (ref, k, lo, b[0], hi, b[1])  # conservative: a superset
+            # ... and not wildly so: within one grid step of the exact box
+            for a in range(3):
+                step = 2.0 ** (int((node["exps"] >> (8 * a)) & 0xFF) - 127)
+                assert b[0][a] - lo[a] < step + 1e-30 and hi[a] - b[1][a] < step + 1e-30
+            lo_all, hi_all = np.minimum(lo_all, b[0]), np.maximum(hi_all, b[1])
+        return lo_all, hi_all
+
+    import sys
+    sys.setrecursionlimit(10000)
+    below(root, 0)
+    assert sorted(seen) == sorted(leaves)  # every reference leaf exactly once
+    return len(wide)
+
+
+@pytest.mark.parametrize("seed", list(range(0, 120, 3)))
+def test_wide_tree_of_random_scenes(hb, seed):
+    sc, _ = scenes.random_everything(seed)
+    _check_wide_tree(hb.HipScene(sc, device=abi.RT_DEVICE_NONE))
+
+
+def test_wide_tree_sizes_and_degenerate_boxes(hb):
+    built = 0
+    for n in (2, 3, 5, 64, 1000, 20000):
+        built += _check_wide_tree(hb.HipScene(scenes.random_spheres(n, seed=n, emissive_every=7), device=abi.RT_DEVICE_NONE))
+    for n in (2, 12, 300, 50000):
+        built += _check_wide_tree(hb.HipScene(scenes.random_triangle_mesh(n, seed=n, extent=4.0, edge=0.4, sampler_res=(4, 4)),
+                                              device=abi.RT_DEVICE_NONE))
+    assert built > 1000
+    # flat boxes (axis-aligned triangles), huge and tiny coordinates side by side
+    sc = scenes.SceneDescription()
+    m = sc.lambertian(sc.solid(0.5), 0.5)
+    rng = np.random.default_rng(3)
+    for i in range(200):
+        a = rng.uniform(-1, 1, 3) * 10.0 ** rng.integers(-6, 7)
+        sc.aacuboid(tuple(a), tuple(a + rng.uniform(0.0, 1.0, 3) * 10.0 ** rng.integers(-8, 5)), m)
+    sc.set_sky(sc.solid(0.5), (0, 0))
+    assert _check_wide_tree(hb.HipScene(sc, device=abi.RT_DEVICE_NONE)) > 100
+    # bounds beyond 2^60 or non-finite: no wide tree (every ray takes the two-child walk)
+    for bad in (3.0e18, float("inf")):
+        sc = scenes.SceneDescription()
+        m = sc.lambertian(sc.solid(0.5), 0.5)
+        for i in range(10):
+            sc.sphere((float(i), 0.0, 0.0), 0.3, m)
+        sc.sphere((bad, 0.0, 0.0), 1.0, m)
+        sc.set_sky(sc.solid(0.5), (0, 0))
+        assert len(hb.HipScene(sc, device=abi.RT_DEVICE_NONE).wide_tree()[0]) == 0
