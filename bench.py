@@ -80,7 +80,7 @@ def source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "raytracing-rust_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":  # the Makefile carries the compiler flags
             h.update(open(os.path.join(csrc, name), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "rt_detmath.h"), "rb").read())
     return h.hexdigest()[:16]
