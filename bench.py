@@ -422,8 +422,12 @@ def main():
                          "note": "achieved = bytes the pruned walk REQUESTS (64 B/node step + 48 B/primitive test, counted live) / kernel time; "
                                  "fabric_GBps_from_pmc = what crossed the fabric (Infinity Cache + HBM, 128-byte lines) in the committed profile "
                                  "of this build: above the requested bytes because a 64-byte node uses half of the line it arrives in"})
-        if w["bytes"]:
-            roof["survey_8d_algorithmic"] = {"bytes_per_sample": w["bytes"], "requested_GBps": w["bytes"] * launch_samples / k_s / 1e9,
+        ab = w["bytes"]
+        ap = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")  # the oracle's own count, when it has been made for this workload
+        if os.path.exists(ap):
+            ab = json.load(open(ap)).get(f"{name}_{WIDTH}x{HEIGHT}_mis", {}).get("bytes_per_sample", ab)
+        if ab:
+            roof["survey_8d_algorithmic"] = {"bytes_per_sample": ab, "requested_GBps": ab * launch_samples / k_s / 1e9,
                                              "note": "requested bytes under REFERENCE traversal semantics (no pruning, oracle-counted); not HBM bytes, not a roofline fraction"}
         out = {
             "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp" if name == "rtweekend1" else f"Msamples/s on {name} {WIDTH}x{HEIGHT}x{SPP}spp",

@@ -251,6 +251,23 @@ struct HipSampler {
 	}
 };
 
+// The output stage on the GPU (crates/output/src/lib.rs:89-97): renders and returns the 8-bit RGB image
+// save_data_to_image would write, `(val.powf(1.0 / gamma) * 255.999) as u8` computed where the frame lives.
+inline std::vector<uint8_t> render_rgb8(const RenderOptions &o, const SimpleCamera &camera, const Bvh &bvh, uint64_t seed = 1,
+                                        uint64_t *rays_shot = nullptr)
+{
+	rt_render_opts opts;
+	rt_render_opts_default(&opts);
+	opts.width = o.width;
+	opts.height = o.height;
+	opts.samples_per_pixel = o.samples_per_pixel;
+	opts.seed = seed;
+	opts.render_method = (int32_t)o.render_method;
+	std::vector<uint8_t> out((size_t)o.width * o.height * 3);
+	check(rt_render_rgb8(bvh.raw(), &camera.raw(), &opts, o.gamma, out.data(), rays_shot));
+	return out;
+}
+
 struct Presentation { // what render_tui keeps: the mean image and the ray total (src/main.rs:160-173)
 	SamplerProgress sampler_progress;
 	Presentation(uint64_t pixel_num) : sampler_progress(pixel_num, 3) {}

@@ -1166,6 +1166,11 @@ hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, c
 {
 	const size_t lds_bytes = (size_t)4 * S.stack_depth * kStackStride * sizeof(uint32_t);
 	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	// deep trees: more than the default 64 KB of dynamic LDS per workgroup (the whole worst-case stack lives in LDS here)
+	hipError_t e = hipFuncSetAttribute(prune ? reinterpret_cast<const void *>(check_hit_kernel<true>) : reinterpret_cast<const void *>(check_hit_kernel<false>),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess)
+		return e;
 	if (prune)
 		hipLaunchKernelGGL(check_hit_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, S,
 		                   static_cast<const DevRayDesc *>(rays), n, static_cast<DevHitRecord *>(out));
@@ -1180,6 +1185,11 @@ hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene
 {
 	const size_t lds_bytes = (size_t)4 * S.stack_depth * kStackStride * sizeof(uint32_t);
 	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	hipError_t e = hipFuncSetAttribute(prune ? reinterpret_cast<const void *>(check_hit_index_kernel<true>)
+	                                         : reinterpret_cast<const void *>(check_hit_index_kernel<false>),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if (e != hipSuccess)
+		return e;
 	if (prune)
 		hipLaunchKernelGGL(check_hit_index_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, S,
 		                   static_cast<const DevRayDesc *>(rays), static_cast<const unsigned long long *>(object_index), n,

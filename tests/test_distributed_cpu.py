@@ -50,7 +50,7 @@ def _worker(rank, world, port, width, height, tile, result_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,width,height,tile", [(2, 50, 30, 8), (3, 33, 17, 4), (2, 16, 8, 8)])
+@pytest.mark.parametrize("world,width,height,tile", [(2, 50, 30, 8), (3, 33, 17, 4), (2, 16, 8, 8), (8, 70, 44, 8)])  # 8 = the node bench.py --gpus 8 runs on
 def test_shard_gather_reassembles_the_frame(tmp_path, world, width, height, tile):
     result = str(tmp_path / "ok.npy")
     port = 29500 + (os.getpid() % 2000) + world
