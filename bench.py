@@ -282,14 +282,24 @@ def main():
         raise SystemExit(f"workload {name} is one rank's shard by definition: run it with --gpus 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP back end has no CPU fallback")
+    # RT_BENCH_REHEARSAL=1: the N ranks share GPU 0 and talk over gloo (RCCL wants one GPU per rank).  Exercises the
+    # launcher, the rank environment, sharded rendering, gather + scatter, the max-over-ranks timing and the JSON line on
+    # a one-GPU box; the number it prints is NOT a measurement (and says so).
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    comm_device = torch.device("cpu") if rehearsal else device
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"  # the latter: rehearse the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")  # only missing in the one-rank rehearsal (RT_BENCH_FORCE_DIST)
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = importlib.import_module("raytracing-rust_amd")
     hb = importlib.import_module("raytracing-rust_amd.hip_backend")
@@ -320,15 +330,18 @@ def main():
     else:
         shard_index, shard_count = rank, world
     sopts = D.shard_opts(opts, shard_index, shard_count)
-    gather = D.ShardGather(opts, rank, world, device) if "shard" not in w else None
+    gather = D.ShardGather(opts, rank, world, comm_device) if "shard" not in w else None
     n_shard_floats = hb.output_floats(sopts)
     shard = torch.zeros(n_shard_floats // 3, 3, dtype=torch.float32, device=device) if gather is None else gather.new_shard_buffer()
-    frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=device) if (rank == 0 and gather is not None) else None
+    frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=comm_device) if (rank == 0 and gather is not None) else None
     d_rays = torch.zeros(1, dtype=torch.int64, device=device)
     stream = torch.cuda.current_stream(device)
+    shard_dev = torch.zeros_like(shard, device=device) if rehearsal else shard
 
     def step():
-        scene.render_device(cam, sopts, shard.data_ptr(), d_rays.data_ptr(), stream.cuda_stream)
+        scene.render_device(cam, sopts, shard_dev.data_ptr(), d_rays.data_ptr(), stream.cuda_stream)
+        if rehearsal:
+            shard.copy_(shard_dev)  # through the host: gloo moves CPU tensors
         return gather.gather(shard, frame) if gather is not None else shard
 
     def barrier():
@@ -348,11 +361,11 @@ def main():
         kernel_ms.append(scene.last_kernel_ms()[0])
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    rays = D.reduce_rays(d_rays.clone(), world)
+    rays = D.reduce_rays(d_rays.clone().to(comm_device), world)
     launch = scene.last_launch_info()
 
     if rank == 0:
@@ -441,7 +454,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else f"synthetic -- REHEARSAL: {world} ranks share one GPU over gloo; not a measurement",
             "config": {"workload": f"{w['label']} {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={w['seed']} ({w['config']})",
                        "parallelism": (f"{world} ranks (one per GPU), 8x8 tiles interleaved t % {world}, replicated BVH, one RCCL gather per frame"
                                        if world > 1 else ("1 GPU" + (f", shard {w['shard'][0]} of {w['shard'][1]}" if "shard" in w else ""))),
