@@ -31,6 +31,10 @@ hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const fl
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
 hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, const void *rays, uint64_t n, void *out);
+#ifdef RT_STATS
+hipError_t launch_trace_queue(int waves, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream, const DevScene &S, const void *rays, uint32_t n, void *out,
+                              uint32_t *counter, unsigned long long *steps, uint32_t cap, uint32_t ovf_depth, uint32_t *ovf);
+#endif
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
 } // namespace rt
@@ -1151,6 +1155,52 @@ int rt_output_save(const char *filename, const float *rgb, uint32_t width, uint3
 }
 
 } // extern "C"
+
+#ifdef RT_STATS
+// diagnostic build only (tests/probes/gpu_trace_queue.py): n rays through the traversal-only persistent kernel at `waves`
+// waves/SIMD with `cap` stack entries per lane in LDS; returns (t, primitive) per ray, the kernel time and the node steps
+extern "C" int rt_debug_trace_queue(rt_scene *s, const rt_ray_desc *rays, uint64_t n, int waves, uint32_t cap, float *out_t, uint32_t *out_prim,
+                                    float *ms, unsigned long long *node_steps)
+{
+	if (!s || !rays || !out_t || !out_prim || n == 0 || n >= (1ull << 31) || s->device == RT_DEVICE_NONE || s->dev.nodes4 == nullptr)
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments (or no wide tree)");
+	HIP_TRY(hipSetDevice(s->device));
+	cap = std::min(std::max(cap, 1u), s->dev.stack_depth);
+	const uint32_t ovf_depth = s->dev.stack_depth - cap;
+	const uint32_t n_blocks = (uint32_t)s->n_cus * (uint32_t)waves;
+	const size_t lds_bytes = (size_t)4 * cap * 64 * 4;
+	void *d_rays = nullptr, *d_out = nullptr, *d_misc = nullptr, *d_ovf = nullptr;
+	HIP_TRY(hipMalloc(&d_rays, n * sizeof(rt_ray_desc)));
+	HIP_TRY(hipMalloc(&d_out, n * 8));
+	HIP_TRY(hipMalloc(&d_misc, 16));
+	HIP_TRY(hipMalloc(&d_ovf, std::max<size_t>(16, (size_t)n_blocks * 256 * ovf_depth * 4)));
+	HIP_TRY(hipMemcpy(d_rays, rays, n * sizeof(rt_ray_desc), hipMemcpyHostToDevice));
+	float best = 1e30f;
+	for (int rep = 0; rep < 3; ++rep) {
+		HIP_TRY(hipMemset(d_misc, 0, 16));
+		HIP_TRY(hipEventRecord(s->ev_start, s->stream));
+		HIP_TRY(launch_trace_queue(waves, n_blocks, lds_bytes, s->stream, s->dev, d_rays, (uint32_t)n, d_out, static_cast<uint32_t *>(d_misc),
+		                           reinterpret_cast<unsigned long long *>(static_cast<char *>(d_misc) + 8), cap, ovf_depth, static_cast<uint32_t *>(d_ovf)));
+		HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
+		HIP_TRY(hipEventSynchronize(s->ev_stop));
+		float t = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&t, s->ev_start, s->ev_stop));
+		best = std::min(best, t);
+	}
+	std::vector<float> tmp(2 * n);
+	HIP_TRY(hipMemcpy(tmp.data(), d_out, n * 8, hipMemcpyDeviceToHost));
+	for (uint64_t i = 0; i < n; ++i) {
+		out_t[i] = tmp[2 * i];
+		std::memcpy(&out_prim[i], &tmp[2 * i + 1], 4);
+	}
+	if (node_steps)
+		HIP_TRY(hipMemcpy(node_steps, static_cast<char *>(d_misc) + 8, 8, hipMemcpyDeviceToHost));
+	if (ms)
+		*ms = best;
+	(void)hipFree(d_rays); (void)hipFree(d_out); (void)hipFree(d_misc); (void)hipFree(d_ovf);
+	return RT_OK;
+}
+#endif
 
 // ---- batch hit queries ----
 static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n, rt_hit_record *out)

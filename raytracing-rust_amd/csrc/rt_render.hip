@@ -1055,6 +1055,131 @@ __global__ __launch_bounds__(256) void check_hit_index_kernel(const DevScene S, 
 	store_record(outr[i], h, m, object_index[i], found);
 }
 
+#ifdef RT_STATS
+// ---- diagnostic build only: a register-lean TRAVERSAL-ONLY persistent kernel (tests/probes/gpu_trace_queue.py).
+// Lanes pull rays from a queue, walk the wide tree (NODE / LEAF voted as in the fine schedule), write (t, primitive) and
+// refill in place.  It holds nothing but the ray, the best hit and the stack, so it can run at up to 8 waves/SIMD: the
+// experiment behind DESIGN.md section 8.1 (what a wavefront split could give the big-tree configurations). ----
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void trace_queue_kernel(const DevScene S, const DevRayDesc *__restrict__ rays, uint32_t n, float2 *__restrict__ out,
+                                                                 uint32_t *__restrict__ counter, unsigned long long *__restrict__ steps_out,
+                                                                 uint32_t stack_cap, uint32_t ovf_depth, uint32_t *__restrict__ ovf)
+{
+	using F = Feat<true, true, false, false>;
+	extern __shared__ __align__(16) uint32_t lds[];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	StackMem SM;
+	SM.cap = stack_cap;
+	SM.ovf_depth = ovf_depth;
+	SM.ovf = ovf;
+	SM.region = lds;
+	uint32_t *stk = lds + wave * (stack_cap * kStackStride) + lane;
+	enum { EMPTY = 0, NODE = 1, LEAF = 2, DONE = 3 };
+	int ph = EMPTY;
+	Ray ray;
+	ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
+	uint32_t node = kRefDone, best_prim = kNoPrim, id = 0;
+	int sp = 0;
+	float best_t = 0.0f;
+	unsigned long long n_steps = 0;
+	uint32_t wq_next = 0, wq_end = 0;
+	auto finish = [&]() {
+		out[id] = make_float2(best_t, __uint_as_float(best_prim));
+		ph = EMPTY;
+	};
+	for (;;) {
+		const unsigned long long need = __ballot(ph == EMPTY);
+		if (need != 0ull) {
+			const uint32_t cnt = (uint32_t)__popcll(need), avail = wq_end - wq_next;
+			uint32_t base = wq_end;
+			if (avail < cnt) {
+				const int leader = __ffsll((long long)need) - 1;
+				uint32_t claimed = 0;
+				if ((int)lane == leader)
+					claimed = atomicAdd(counter, 64u);
+				base = __shfl(claimed, leader);
+			}
+			if (ph == EMPTY) {
+				const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+				id = r < avail ? wq_next + r : base + (r - avail);
+				if (id >= n) {
+					ph = DONE;
+				} else {
+					ray = ray_new<F>(v3(rays[id].origin[0], rays[id].origin[1], rays[id].origin[2]),
+					                 v3(rays[id].direction[0], rays[id].direction[1], rays[id].direction[2]));
+					best_t = 0.0f;
+					best_prim = kNoPrim;
+					sp = 0;
+					node = S.root4_ref;
+					ph = ref_is_leaf(node) ? LEAF : NODE;
+				}
+			}
+			if (avail < cnt) {
+				wq_next = base + (cnt - avail);
+				wq_end = base + 64u;
+			} else {
+				wq_next += cnt;
+			}
+		}
+		const uint32_t c_node = (uint32_t)__popcll(__ballot(ph == NODE)), c_leaf = (uint32_t)__popcll(__ballot(ph == LEAF));
+		if (c_node + c_leaf == 0u) {
+			if (__ballot(ph == EMPTY) == 0ull)
+				break;
+			continue;
+		}
+		if (c_leaf >= kDrainLanes || c_node == 0u) {
+			if (ph == LEAF) {
+				if (leaf_box_hit(S, node, ray))
+					closest_in_leaf<F>(S, ray, node, best_t, best_prim);
+				if (sp == 0) {
+					finish();
+				} else {
+					--sp;
+					node = ovf_depth == 0u ? stack_load<false>(SM, stk, sp) : stack_load<true>(SM, stk, sp);
+					ph = ref_is_leaf(node) ? LEAF : NODE;
+				}
+			}
+		} else {
+#pragma unroll 1
+			for (int step = 0; step < kNodeStepsPerVote; ++step) {
+				if (ph == NODE) {
+					n_steps += 1;
+					if (ovf_depth == 0u)
+						node = descend4<true, false>(S, SM, ray, node, stk, sp, best_prim != kNoPrim, best_t);
+					else
+						node = descend4<true, true>(S, SM, ray, node, stk, sp, best_prim != kNoPrim, best_t);
+					if (node == kRefDone)
+						finish();
+					else if (ref_is_leaf(node))
+						ph = LEAF;
+				}
+			}
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		n_steps += __shfl_down(n_steps, off);
+	if (lane == 0u)
+		atomicAdd(steps_out, n_steps);
+}
+
+hipError_t launch_trace_queue(int waves, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream, const DevScene &S, const void *rays, uint32_t n, void *out,
+                              uint32_t *counter, unsigned long long *steps, uint32_t cap, uint32_t ovf_depth, uint32_t *ovf)
+{
+#define RT_TQ(W) \
+	if (waves == W) { \
+		hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_queue_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+		if (e_ != hipSuccess) \
+			return e_; \
+		hipLaunchKernelGGL(trace_queue_kernel<W>, dim3(n_blocks), dim3(256), lds_bytes, stream, S, static_cast<const DevRayDesc *>(rays), n, \
+		                   static_cast<float2 *>(out), counter, steps, cap, ovf_depth, ovf); \
+		return hipGetLastError(); \
+	}
+	RT_TQ(3) RT_TQ(4) RT_TQ(5) RT_TQ(6) RT_TQ(8)
+#undef RT_TQ
+	return hipErrorInvalidValue;
+}
+#endif
+
 // ---- launchers (called from rt_api.cpp) ----
 #ifdef RT_STATS
 extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
