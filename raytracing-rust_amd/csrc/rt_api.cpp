@@ -66,7 +66,8 @@ static int hip_fail(hipError_t e, const char *what)
 //   but only ties on sphere-only scenes even at 16 k (96 vs 106 ms): sphere leaves are cheap, triangle leaves
 //   are long and divergent.
 constexpr uint32_t kPruneAbove = 100;
-constexpr uint32_t kFineAboveTriangles = 2048;
+constexpr uint32_t kFineAboveTriangles = 4096; // round 2, with the wide walk under both schedules (8 spp 1080p, MIS coarse / fine):
+                                               // 2 000 triangles 11.9 / 13.4 ms, 4 000: 14.9 / 16.2, 10 000: 30.2 / 26.2 (naive crosses near 3 000)
 constexpr uint32_t kFineAboveSpheres = 32768;
 
 struct rt_scene {

@@ -1,15 +1,17 @@
+"""Where the schedules / walks cross over on random triangle meshes (1080p, 8 spp): coarse vs fine schedule, wide vs
+two-child walk.  python tests/probes/gpu_crossover_mesh.py"""
 import importlib, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend"); abi = pkg.abi
 import scenes
-for n, edge in ((1000, 1.0), (10000, 0.5), (100000, 0.2), (1000000, 0.05), (200000, 0.3)):
+for n, edge in ((150, 2.0), (500, 1.5), (1000, 1.0), (2000, 0.8), (4000, 0.6), (10000, 0.5), (100000, 0.2)):
     g = hb.HipScene(scenes.random_triangle_mesh(n, seed=42, edge=edge))
     cam = hb.camera_new(**scenes.MESH_CAMERA)
     row = []
     for method in (1, 0):
-        for (trav, sched) in ((1, 0), (1, 1)):
-            g.set_tuning(abi.RT_TUNE_TRAVERSAL, trav); g.set_tuning(abi.RT_TUNE_SCHEDULE, sched)
+        for (trav, sched, walk) in ((1, 0, 0), (1, 0, 1), (1, 1, 0)):
+            g.set_tuning(abi.RT_TUNE_TRAVERSAL, trav); g.set_tuning(abi.RT_TUNE_SCHEDULE, sched); g.set_tuning(abi.RT_TUNE_WALK, walk)
             o = abi.default_render_opts(1920, 1080, 8, method=method)
             g.render(cam, o); g.render(cam, o)
             row.append(g.last_kernel_ms()[0])
-    print(f"tris={n:8d} edge={edge}: MIS pruned+coarse {row[0]:8.2f} pruned+fine {row[1]:8.2f} | naive {row[2]:8.2f} {row[3]:8.2f}", flush=True)
+    print(f"tris={n:7d} edge={edge}: MIS coarse+wide {row[0]:7.2f} coarse+two-child {row[1]:7.2f} fine+wide {row[2]:7.2f} | naive {row[3]:7.2f} {row[4]:7.2f} {row[5]:7.2f}", flush=True)
