@@ -25,7 +25,7 @@ RT_SPLIT_SAH, RT_SPLIT_MIDDLE, RT_SPLIT_EQUAL_COUNTS = range(3)
 # enum RenderMethod (samplers/mod.rs:43-47)
 RT_METHOD_NAIVE, RT_METHOD_MIS = range(2)
 RT_LAYOUT_FRAME, RT_LAYOUT_SHARD = range(2)
-RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS, RT_TUNE_SCHEDULE, RT_TUNE_WALK, RT_TUNE_STACK_CAP = range(6)
+RT_TUNE_TRAVERSAL, RT_TUNE_FEATURE_SET, RT_TUNE_SCENE_IN_LDS, RT_TUNE_SCHEDULE, RT_TUNE_WALK, RT_TUNE_STACK_CAP, RT_TUNE_EXCHANGE = range(7)
 
 NO_INDEX = 0xFFFFFFFFFFFFFFFF  # usize::MAX
 RT_DEVICE_NONE = -1  # rt_scene_create: Bvh::new on the host only (no GPU touched, nothing can be rendered)

@@ -23,10 +23,13 @@ namespace rt {
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block, uint32_t stack_cap);
 uint32_t render_waves_per_simd(int feature_set, bool fine);
 uint32_t render_block_threads(int feature_set, bool fine);
-hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu);
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg);
+bool render_exchange_available(int method, bool prune, bool fine, int feature_set);
+size_t render_exchange_lds_bytes(uint32_t slots);
+uint32_t render_exchange_max_slots();
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf);
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
@@ -100,6 +103,7 @@ struct rt_scene {
 	size_t max_lds = 65536;
 	rt_launch_info last_launch{};
 	uint32_t stack_cap_override = 0; // RT_TUNE_STACK_CAP
+	int exchange_mode = 0;           // RT_TUNE_EXCHANGE
 	uint32_t *d_stack_ovf = nullptr; // traversal-stack overflow area (deep trees under the fine schedule), grown on demand
 	size_t stack_ovf_words = 0;
 	uint8_t *d_rgb8 = nullptr; // rt_render_rgb8: the quantised frame
@@ -384,6 +388,11 @@ int rt_scene_set_tuning(rt_scene *s, int key, int value)
 			return fail(RT_ERR_INVALID_ARGUMENT, "stack cap must be 0 (automatic) or 1..96 entries");
 		s->stack_cap_override = (uint32_t)value;
 		return RT_OK;
+	case RT_TUNE_EXCHANGE:
+		if (value < 0 || value > 1)
+			return fail(RT_ERR_INVALID_ARGUMENT, "exchange must be 0 (off) or 1 (on where the kernel has it)");
+		s->exchange_mode = value;
+		return RT_OK;
 	case RT_TUNE_WALK:
 		if (value < 0 || value > 1)
 			return fail(RT_ERR_INVALID_ARGUMENT, "walk must be 0 (automatic) or 1 (two-child walk for every ray)");
@@ -666,12 +675,12 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu));
+	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu, false));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
 		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, block_threads / 64u, stack_cap);
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
-		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with) == hipSuccess &&
+		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with, false) == hipSuccess &&
 		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
 			sky_lds = true;
 			lds_bytes = lds_with;
@@ -681,6 +690,25 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.sky_in_lds = sky_lds ? 1u : 0u;
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
+	// RT_TUNE_EXCHANGE: the workgroup's pool of parked path states sits behind the stacks (rt_render.hip, XCHG) and gets
+	// the LDS that is left at this occupancy -- it never costs a resident workgroup or the sky tables their place
+	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, s->feature_set);
+	P.xchg_slots = 0;
+	if (xchg) {
+		const size_t share = s->max_lds / (size_t)blocks_per_cu; // max_lds is the LDS of one CU
+		uint32_t slots = render_exchange_max_slots();
+		while (slots >= 16u && lds_bytes + render_exchange_lds_bytes(slots) > share)
+			slots -= 4u;
+		int blocks_x = 0;
+		if (slots >= 16u &&
+		    render_occupancy(o->render_method, prune, fine, sky_lds, s->feature_set, lds_bytes + render_exchange_lds_bytes(slots), &blocks_x, true) == hipSuccess &&
+		    blocks_x >= blocks_per_cu) {
+			P.xchg_slots = slots;
+			lds_bytes += render_exchange_lds_bytes(slots);
+		} else {
+			xchg = false;
+		}
+	}
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
 	const uint64_t blocks_needed = ((uint64_t)P.n_items + render_block_threads(s->feature_set, fine) - 1) / render_block_threads(s->feature_set, fine);
 	if (n_blocks > blocks_needed)
@@ -721,8 +749,9 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		static const char *const feat_names[3] = {"rt::Feat<false, false, false, false>", "rt::Feat<true, true, false, false>",
 		                                          "rt::Feat<true, true, true, true>"};
 		// pick_render (rt_render.hip) folds these: naive never stages the sky, fine implies pruned
-		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s>", (int)o->render_method, prune ? "true" : "false",
-		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set]);
+		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s%s>", (int)o->render_method, prune ? "true" : "false",
+		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set],
+		              xchg ? ", true" : "");
 	}
 	if (P.stack_ovf_depth != 0u) { // grown on first use only (like the sample_split scratch: not capturable on that call)
 		const size_t need = (size_t)n_blocks * block_threads * P.stack_ovf_depth;
@@ -737,7 +766,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
 	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
-	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf));
+	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
 		HIP_TRY(launch_combine(stream, P, s->d_partial, d_out_rgb));

@@ -145,7 +145,20 @@ template <class F, bool FINE = false> struct KernelShape {
 __device__ unsigned long long g_stats[64];
 #endif
 
-template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F>
+// Cross-wave exchange of path state (XCHG, coarse MIS kernels, opt-in through RT_TUNE_EXCHANGE): a lane whose path
+// waits for the super-phase its wave is NOT about to run parks its state in a workgroup pool in LDS and takes a parked
+// state of the kind the wave does run, so both super-phases see full waves.  A path's whole state travels (40 dwords for
+// a path between bounces, 10 for a pixel between samples), the pixel with it, so a pixel's samples are still folded in
+// order and every pixel keeps its own random streams: which lane finishes a pixel cannot change it.  The pool is
+// guarded by ONE try-lock: a wave that does not get it skips the exchange for this iteration and votes as usual --
+// nothing ever waits, so nothing can hang.
+// Records are read and written 16 bytes at a time; the strides (in dwords) are = 4 * odd mod 64... chosen so that the 16 lanes
+// one ds_*_b128 pass serves land on 16 different groups of four banks: 44 = 4 * 11, 12 = 4 * 3.
+constexpr uint32_t kXchgBStride = 44, kXchgPStride = 12; // dwords per parked path (40 used) / pixel (10 used)
+constexpr uint32_t kXchgMaxSlots = 64;                   // parked states of each kind per workgroup, at most (DevRenderParams.xchg_slots)
+constexpr uint32_t kXchgMinLanes = 4;                    // fewer idle lanes than this are not worth the trade
+
+template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F, bool XCHG = false>
 __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter, uint32_t *__restrict__ stack_ovf)
@@ -209,6 +222,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	SM.ovf = stack_ovf;
 	SM.region = lds + sky_words + blob_words;
 	uint32_t *stk = SM.region + wave * (P.stack_cap * kStackStride) + lane;
+	// exchange pool (XCHG): [lock, parked paths, parked pixels, pad] [paths: word k of slot s at k * slots + s] [pixels likewise]
+	uint32_t *pool = lds + (((uint32_t)(SM.region - lds) + (blockDim.x >> 6) * (P.stack_cap * kStackStride) + 3u) & ~3u);
+	if (XCHG) {
+		if (threadIdx.x < 4u)
+			pool[threadIdx.x] = 0u;
+		__syncthreads();
+	}
 
 	const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
 	const uint64_t sample_begin = ((uint64_t)P.sample_begin_hi << 32) | P.sample_begin_lo;
@@ -639,6 +659,142 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 		}
 	};
 
+	// XCHG -- trade with the workgroup's pool before the wave votes.  Between iterations of the coarse MIS schedule a
+	// lane is in exactly one of four states: PH_GEN (a pixel between samples), PH_LIGHT (a path between bounces),
+	// PH_NEED_PIXEL, PH_DONE.  The wave picks the super-phase it could run FULLER after a trade -- BOUNCE by swapping its
+	// pixels for parked paths, PRIMARY by parking its paths and taking parked (or fresh) pixels -- so the level of the
+	// pool steers the waves of a workgroup into the two roles in the proportion the scene asks for.
+	auto exchange = [&]() {
+		const uint32_t slots = P.xchg_slots;
+		const unsigned long long mB = __ballot(ph == PH_LIGHT), mP = __ballot(ph == PH_GEN);
+		const unsigned long long mD = __ballot(ph == PH_DONE), mE = mD | __ballot(ph == PH_NEED_PIXEL);
+		const uint32_t nb = (uint32_t)__popcll(mB), np = (uint32_t)__popcll(mP), ne = (uint32_t)__popcll(mE);
+		const uint32_t nn = ne - (uint32_t)__popcll(mD);
+		const bool fresh = mD == 0ull; // the frame still has unclaimed pixels (as far as this wave knows)
+		const uint32_t peekB = __hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const uint32_t peekP = __hip_atomic_load(&pool[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		// lanes each super-phase would run on after the trade
+		const uint32_t bounce_lanes = nb + min(min(np, slots - peekP) + ne, peekB);
+		const uint32_t primary_lanes = np + nn + min(nb, fresh ? slots - peekB : min(slots - peekB, peekP));
+		const bool will_bounce = (np + nn) == 0u || (bounce_lanes >= kLightPhaseThreshold && bounce_lanes >= primary_lanes);
+		bool want;
+		if (will_bounce)
+			want = ((np >= kXchgMinLanes || ne != 0u) && peekB != 0u) || (nb == 0u && np == 0u && peekP != 0u);
+		else
+			want = (nb >= kXchgMinLanes && peekB < slots && (fresh || peekP != 0u)) || (ne != 0u && peekP != 0u);
+		if (!want)
+			return;
+		uint32_t got = 0u;
+		if (lane == 0u) {
+			uint32_t expect = 0u;
+			got = __hip_atomic_compare_exchange_strong(&pool[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+		}
+		if (__shfl(got, 0) == 0u)
+			return; // somebody else is trading: vote with what the wave has
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		uint32_t cB = pool[1], cP = pool[2];
+		uint32_t *poolB = pool + 4, *poolP = pool + 4 + kXchgBStride * slots;
+		auto park_path = [&](uint32_t slot) {
+			uint4 *d = reinterpret_cast<uint4 *>(poolB + slot * kXchgBStride);
+			const uint32_t fl = (hit.has_uv ? 1u : 0u) | (hit.out ? 2u : 0u) | (primary ? 4u : 0u);
+			d[0] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+			d[1] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), __float_as_uint(outp.x));
+			d[2] = make_uint4(__float_as_uint(outp.y), __float_as_uint(outp.z), __float_as_uint(wo.x), __float_as_uint(wo.y));
+			d[3] = make_uint4(__float_as_uint(wo.z), __float_as_uint(hit.t), __float_as_uint(hit.point.x), __float_as_uint(hit.point.y));
+			d[4] = make_uint4(__float_as_uint(hit.point.z), __float_as_uint(hit.error.x), __float_as_uint(hit.error.y), __float_as_uint(hit.error.z));
+			d[5] = make_uint4(__float_as_uint(hit.normal.x), __float_as_uint(hit.normal.y), __float_as_uint(hit.normal.z), __float_as_uint(hit.uvx));
+			d[6] = make_uint4(__float_as_uint(hit.uvy), fl, mat, depth);
+			d[7] = make_uint4(ray_count, __float_as_uint(mean.x), __float_as_uint(mean.y), __float_as_uint(mean.z));
+			d[8] = make_uint4(sample_local, out_index, pixel_index, px);
+			d[9] = make_uint4(py, chunk_begin, chunk_n, 0u);
+		};
+		auto take_path = [&](uint32_t slot) {
+			const uint4 *d = reinterpret_cast<const uint4 *>(poolB + slot * kXchgBStride);
+			const uint4 a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3], a4 = d[4], a5 = d[5], a6 = d[6], a7 = d[7], a8 = d[8], a9 = d[9];
+			rng.s0 = a0.x; rng.s1 = a0.y; rng.s2 = a0.z; rng.s3 = a0.w;
+			thr = v3(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z));
+			outp = v3(__uint_as_float(a1.w), __uint_as_float(a2.x), __uint_as_float(a2.y));
+			wo = v3(__uint_as_float(a2.z), __uint_as_float(a2.w), __uint_as_float(a3.x));
+			hit.t = __uint_as_float(a3.y);
+			hit.point = v3(__uint_as_float(a3.z), __uint_as_float(a3.w), __uint_as_float(a4.x));
+			hit.error = v3(__uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
+			hit.normal = v3(__uint_as_float(a5.x), __uint_as_float(a5.y), __uint_as_float(a5.z));
+			hit.uvx = __uint_as_float(a5.w);
+			hit.uvy = __uint_as_float(a6.x);
+			hit.has_uv = (a6.y & 1u) != 0u; hit.out = (a6.y & 2u) != 0u; primary = (a6.y & 4u) != 0u;
+			mat = a6.z; depth = a6.w;
+			ray_count = a7.x;
+			mean = v3(__uint_as_float(a7.y), __uint_as_float(a7.z), __uint_as_float(a7.w));
+			sample_local = a8.x; out_index = a8.y; pixel_index = a8.z; px = a8.w;
+			py = a9.x; chunk_begin = a9.y; chunk_n = a9.z;
+			ph = PH_LIGHT;
+		};
+		auto park_pixel = [&](uint32_t slot) {
+			uint4 *d = reinterpret_cast<uint4 *>(poolP + slot * kXchgPStride);
+			d[0] = make_uint4(__float_as_uint(mean.x), __float_as_uint(mean.y), __float_as_uint(mean.z), sample_local);
+			d[1] = make_uint4(out_index, pixel_index, px, py);
+			d[2] = make_uint4(chunk_begin, chunk_n, 0u, 0u);
+		};
+		auto take_pixel = [&](uint32_t slot) {
+			const uint4 *d = reinterpret_cast<const uint4 *>(poolP + slot * kXchgPStride);
+			const uint4 a0 = d[0], a1 = d[1], a2 = d[2];
+			mean = v3(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z));
+			sample_local = a0.w; out_index = a1.x; pixel_index = a1.y; px = a1.z; py = a1.w;
+			chunk_begin = a2.x; chunk_n = a2.y;
+			ph = PH_GEN;
+		};
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const uint32_t rB = (uint32_t)__popcll(mB & below), rP = (uint32_t)__popcll(mP & below), rE = (uint32_t)__popcll(mE & below);
+		const bool is_e = (mE >> lane & 1ull) != 0ull;
+		if (!will_bounce) {
+			// PRIMARY next: the wave's paths between bounces would idle.  Park them; a vacated lane takes a parked pixel if
+			// there is one, else asks for a fresh one -- but only while fresh pixels exist: after that a path is parked
+			// only against a pixel taken, so the pool cannot fill with work nobody is left to run.
+			uint32_t can = nb >= kXchgMinLanes ? min(nb, slots - cB) : 0u;
+			if (!fresh)
+				can = min(can, cP);
+			if (ph == PH_LIGHT && rB < can) {
+				park_path(cB + rB);
+				if (rB < cP)
+					take_pixel(cP - 1u - rB);
+				else
+					ph = PH_NEED_PIXEL;
+			}
+			cB += can;
+			cP -= min(can, cP);
+			const uint32_t te = min(ne, cP); // lanes with nothing to do take parked pixels
+			if (is_e && rE < te)
+				take_pixel(cP - 1u - rE);
+			cP -= te;
+		} else {
+			// BOUNCE next: the wave's pixels between samples would idle.  Each swaps with a parked path, one for one; lanes
+			// with nothing to do just take paths.
+			const uint32_t swaps = np >= kXchgMinLanes ? min(min(np, cB), slots - cP) : 0u;
+			if (ph == PH_GEN && rP < swaps) {
+				park_pixel(cP + rP);
+				take_path(cB - 1u - rP);
+			}
+			cB -= swaps;
+			cP += swaps;
+			const uint32_t te = min(ne, cB);
+			if (is_e && rE < te)
+				take_path(cB - 1u - rE);
+			cB -= te;
+			if (nb == 0u && np == 0u && te == 0u) { // the tail of the frame: a wave with nothing at all takes pixels too
+				const uint32_t tp = min(ne, cP);
+				if (is_e && rE < tp)
+					take_pixel(cP - 1u - rE);
+				cP -= tp;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (lane == 0u) {
+			pool[1] = cB;
+			pool[2] = cP;
+			__hip_atomic_store(&pool[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	};
+
 #ifdef RT_STATS
 	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
 	unsigned long long st_sect[9] = {}, st_mark = wall_clock64();
@@ -647,6 +803,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
 	for (;;) {
+		if (XCHG && METHOD == 1 && !FINE)
+			exchange();
 		// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
 		// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
 		// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and
@@ -786,8 +944,14 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			const uint32_t n_light = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
 			const uint32_t n_trace = (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
 			if (n_light + n_trace == 0u) {
-				if (__ballot(ph == PH_NEED_PIXEL) == 0ull)
+				if (__ballot(ph == PH_NEED_PIXEL) == 0ull) {
+					if (XCHG && METHOD == 1) { // parked work left?  (a later push comes from a wave that is still alive and will drain it itself)
+						if (__hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
+						    __hip_atomic_load(&pool[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u)
+							continue;
+					}
 					break;
+				}
 				continue;
 			}
 			const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
@@ -1231,8 +1395,13 @@ typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams
 using FeatSpheres = Feat<false, false, false, false>; // spheres, Lambertian/Emit, Solid/Lerp, sky is the only light (rtweekend1)
 using FeatSimple = Feat<true, true, false, false>;    // + triangles and emissive primitives (overshadowed, the synthetic meshes)
 
-template <class F> static render_fn pick_render_f(int method, bool prune, bool fine, bool sky_lds)
+template <class F> static render_fn pick_render_f(int method, bool prune, bool fine, bool sky_lds, bool xchg)
 {
+	if (xchg) { // built for the coarse exhaustive MIS kernels (configs 2 and 3)
+		if (method == 1 && !prune && !fine)
+			return sky_lds ? render_kernel<1, false, false, true, F, true> : render_kernel<1, false, false, false, F, true>;
+		return nullptr;
+	}
 #define RT_PICK(M, P, G, L) \
 	if (method == M && prune == P && fine == G && sky_lds == L) \
 		return render_kernel<M, P, G, L, F>;
@@ -1251,22 +1420,26 @@ template <class F> static render_fn pick_render_f(int method, bool prune, bool f
 }
 
 // feature_set: 0 spheres-only, 1 simple, 2 full
-static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, int feature_set)
+static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, bool xchg = false)
 {
 	if (method == 0)
 		sky_lds = false; // the naive integrator never touches the sky tables
 	if (fine)
 		prune = true; // the fine schedule is only built with the pruned walk
 	if (feature_set == 0)
-		return pick_render_f<FeatSpheres>(method, prune, fine, sky_lds);
+		return pick_render_f<FeatSpheres>(method, prune, fine, sky_lds, xchg);
 	if (feature_set == 1)
-		return pick_render_f<FeatSimple>(method, prune, fine, sky_lds);
-	return pick_render_f<FeatFull>(method, prune, fine, sky_lds);
+		return pick_render_f<FeatSimple>(method, prune, fine, sky_lds, xchg);
+	return pick_render_f<FeatFull>(method, prune, fine, sky_lds, xchg);
 }
+bool render_exchange_available(int method, bool prune, bool fine, int feature_set) { (void)feature_set; return method == 1 && !prune && !fine; }
+// LDS of a pool of `slots` parked paths + pixels (incl. the header and the slack of aligning it to 16 bytes)
+size_t render_exchange_lds_bytes(uint32_t slots) { return (size_t)(4u + 4u + (kXchgBStride + kXchgPStride) * slots) * sizeof(uint32_t); }
+uint32_t render_exchange_max_slots() { return kXchgMaxSlots; }
 
-hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu)
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg)
 {
-	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
+	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
 		return hipErrorInvalidValue;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1277,9 +1450,9 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf)
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg)
 {
-	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set);
+	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
 		return hipErrorInvalidValue;
 	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter,

@@ -173,6 +173,7 @@ struct DevRenderParams {
 	uint32_t scene_in_lds;    // the scene blob is staged in LDS (tiny scenes)
 	uint32_t stack_cap;       // traversal stack entries per lane kept in LDS (rt_intersect.h StackMem)
 	uint32_t stack_ovf_depth; // ... and in the global overflow area (0: the LDS part covers the worst case)
+	uint32_t xchg_slots;      // RT_TUNE_EXCHANGE: parked paths / pixels the workgroup's pool holds (rt_render.hip, XCHG)
 };
 
 } // namespace rt

@@ -1,16 +1,19 @@
-"""Schedule statistics from the -DRT_STATS diagnostic build (RT_HIP_LIB=.../librt_hip_stats.so)."""
-import ctypes as C, importlib, sys
+"""Schedule statistics from the -DRT_STATS diagnostic build (RT_HIP_LIB=.../librt_hip_stats.so).
+RT_EXCHANGE=1 in the environment turns RT_TUNE_EXCHANGE on."""
+import ctypes as C, importlib, os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 pkg = importlib.import_module("raytracing-rust_amd"); hb = importlib.import_module("raytracing-rust_amd.hip_backend"); abi = pkg.abi
 import scenes
 for name in ("rtweekend1", "overshadowed"):
     ls = scenes.load_ssml(name); g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
+    g.set_tuning(abi.RT_TUNE_EXCHANGE, int(os.environ.get("RT_EXCHANGE", "0")))
     o = abi.default_render_opts(1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 64)
     o.sample_split = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     out = (C.c_ulonglong * 64)()
     hb.lib().rt_debug_stats(out, 1)
     img, rays = g.render(cam, o)
     hb.lib().rt_debug_stats(out, 1)
+    print(f"   kernel {g.last_kernel_ms()[0]:.2f} ms  {g.last_launch_info()['kernel']}")
     ti, ta, li, la, gen = out[0], out[1], out[2], out[3], out[4]
     sect = [out[40 + k] for k in range(9)]
     tot = max(1, sum(sect))
