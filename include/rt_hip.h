@@ -283,9 +283,11 @@ int rt_scene_set_traversal(rt_scene *scene, int mode);
  *                         tree for every ray
  *   RT_TUNE_STACK_CAP     0 automatic; n: keep at most n traversal-stack entries per lane in LDS, the rest of the
  *                         tree's worst case in the global overflow area (exercises that path on small trees)
- *   RT_TUNE_EXCHANGE      0 off (default); 1: under the coarse schedule with MIS and exhaustive traversal (feature sets
- *                         0 and 1) the waves of a workgroup trade parked path states through LDS, so that each
- *                         super-phase runs on full waves.  Same pixels either way; other kernels ignore it */
+ *   RT_TUNE_EXCHANGE      0 off (default); 1: the waves of a workgroup trade whole lane states (path, pixel, random
+ *                         stream) through pools in LDS -- under the coarse schedule with MIS and exhaustive traversal so
+ *                         that each super-phase runs on full waves, under the fine schedule so that one wave of a
+ *                         512-thread workgroup shades what the other seven walk.  Same pixels either way (measured
+ *                         slower on every workload so far); other kernels ignore it */
 typedef enum rt_tuning_key { RT_TUNE_TRAVERSAL = 0, RT_TUNE_FEATURE_SET = 1, RT_TUNE_SCENE_IN_LDS = 2, RT_TUNE_SCHEDULE = 3, RT_TUNE_WALK = 4,
                              RT_TUNE_STACK_CAP = 5, RT_TUNE_EXCHANGE = 6 } rt_tuning_key;
 int rt_scene_set_tuning(rt_scene *scene, int key, int value);

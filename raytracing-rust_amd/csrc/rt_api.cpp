@@ -22,7 +22,8 @@
 namespace rt {
 size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_t waves_per_block, uint32_t stack_cap);
 uint32_t render_waves_per_simd(int feature_set, bool fine);
-uint32_t render_block_threads(int feature_set, bool fine);
+uint32_t render_block_threads(int feature_set, bool fine, bool xchg = false);
+size_t render_exchange_fine_lds_bytes(uint32_t waves_per_block);
 hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg);
 bool render_exchange_available(int method, bool prune, bool fine, int feature_set);
 size_t render_exchange_lds_bytes(uint32_t slots);
@@ -656,7 +657,12 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	const bool scene_lds = !fine && s->dev.blob_bytes != 0u && s->scene_lds_allowed;
 	P.scene_in_lds = scene_lds ? 1u : 0u;
 	bool sky_lds = false;
-	const uint32_t block_threads = render_block_threads(s->feature_set, fine);
+	// RT_TUNE_EXCHANGE (rt_render.hip, XCHG).  Fine schedule: 512-thread workgroups whose waves trade whole lane states
+	// through two record pools behind the stacks; coarse MIS kernels: decided below, once the occupancy is known
+	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, s->feature_set);
+	const bool xchg_fine = xchg && fine;
+	const uint32_t block_threads = render_block_threads(s->feature_set, fine, xchg_fine);
+	const size_t fine_pool_bytes = xchg_fine ? render_exchange_fine_lds_bytes(block_threads / 64u) : 0;
 	// Traversal stacks: one LDS column per lane.  The worst case of a deep tree (three pending siblings per level of
 	// the wide tree) is far above what walks reach, and LDS sized for it would cost resident waves; under the fine
 	// schedule the LDS part is capped at the share a workgroup gets at the occupancy its register budget allows, the
@@ -664,23 +670,24 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	uint32_t stack_cap = s->dev.stack_depth;
 	if (fine) {
 		const uint32_t blocks_wanted = std::max(1u, render_waves_per_simd(s->feature_set, true) * 256u / block_threads);
-		const uint32_t fit = (uint32_t)(s->max_lds / blocks_wanted) / ((block_threads / 64u) * 64u * 4u);
+		const size_t share = s->max_lds / blocks_wanted;
+		const uint32_t fit = (uint32_t)((share > fine_pool_bytes ? share - fine_pool_bytes : 0) / ((block_threads / 64u) * 64u * 4u));
 		stack_cap = std::min(stack_cap, std::max(8u, fit));
 	}
 	if (fine && s->stack_cap_override != 0u) // (coarse kernels keep the whole stack in LDS and walk without capacity checks)
 		stack_cap = std::min(s->dev.stack_depth, s->stack_cap_override);
 	P.stack_cap = stack_cap;
 	P.stack_ovf_depth = s->dev.stack_depth - stack_cap;
-	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, block_threads / 64u, stack_cap);
+	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu, false));
+	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu, xchg_fine));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, block_threads / 64u, stack_cap);
+		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
-		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with, false) == hipSuccess &&
+		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with, xchg_fine) == hipSuccess &&
 		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
 			sky_lds = true;
 			lds_bytes = lds_with;
@@ -692,9 +699,8 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
 	// RT_TUNE_EXCHANGE: the workgroup's pool of parked path states sits behind the stacks (rt_render.hip, XCHG) and gets
 	// the LDS that is left at this occupancy -- it never costs a resident workgroup or the sky tables their place
-	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, s->feature_set);
 	P.xchg_slots = 0;
-	if (xchg) {
+	if (xchg && !fine) {
 		const size_t share = s->max_lds / (size_t)blocks_per_cu; // max_lds is the LDS of one CU
 		uint32_t slots = render_exchange_max_slots();
 		while (slots >= 16u && lds_bytes + render_exchange_lds_bytes(slots) > share)
@@ -710,7 +716,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		}
 	}
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
-	const uint64_t blocks_needed = ((uint64_t)P.n_items + render_block_threads(s->feature_set, fine) - 1) / render_block_threads(s->feature_set, fine);
+	const uint64_t blocks_needed = ((uint64_t)P.n_items + block_threads - 1) / block_threads;
 	if (n_blocks > blocks_needed)
 		n_blocks = blocks_needed ? blocks_needed : 1;
 
@@ -738,7 +744,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		L.sky_in_lds = sky_lds ? 1 : 0;
 		L.scene_in_lds = scene_lds ? 1 : 0;
 		L.feature_set = s->feature_set;
-		L.block_threads = render_block_threads(s->feature_set, fine);
+		L.block_threads = block_threads;
 		L.n_blocks = (uint32_t)n_blocks;
 		L.blocks_per_cu = (uint32_t)blocks_per_cu;
 		L.waves_per_simd = (uint32_t)blocks_per_cu * L.block_threads / 256u;

@@ -49,7 +49,8 @@ enum : int {
 	PH_NARROW = 6,     // fine schedule only: an irregular ray (rt_intersect.h) runs the two-child walk to its end
 	PH_COUNT = 7,
 	PH_NEED_PIXEL = 7, // served at the top of every iteration (one atomic per wave), not voted
-	PH_DONE = 8
+	PH_DONE = 8,
+	PH_WALK = 9        // fine schedule with the exchange only: a walk waiting to start (between two iterations, never voted)
 };
 
 // coarse schedule: the LIGHT super-phase runs once this many lanes of the wave wait for it
@@ -126,12 +127,13 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 // they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1); so do the simple
 // variants under the coarse schedule.  Fine-schedule kernels keep 256 threads (their LDS goes to the
 // traversal stacks) at 4 waves per SIMD, full-feature coarse kernels 3.
-template <class F, bool FINE = false> struct KernelShape {
+template <class F, bool FINE = false, bool XCHG = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
 	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? RT_FULL_FINE_WAVES : RT_FULL_WAVES)
 	                                      : (spheres_only ? RT_SPHERES_WAVES : (FINE ? RT_SIMPLE_FINE_WAVES : RT_SIMPLE_COARSE_WAVES));
-	static constexpr int block = spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256);
+	// (fine schedule with the exchange: eight waves share the pools of walk starts and walk results, one of them shades)
+	static constexpr int block = (FINE && XCHG) ? 512 : (spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256));
 };
 
 #ifdef RT_STATS
@@ -157,9 +159,27 @@ __device__ unsigned long long g_stats[64];
 constexpr uint32_t kXchgBStride = 44, kXchgPStride = 12; // dwords per parked path (40 used) / pixel (10 used)
 constexpr uint32_t kXchgMaxSlots = 64;                   // parked states of each kind per workgroup, at most (DevRenderParams.xchg_slots)
 constexpr uint32_t kXchgMinLanes = 4;                    // fewer idle lanes than this are not worth the trade
+// Fine schedule (big trees): the short phases (GEN / SHADE / LIGHT / SCATTER) run on a handful of lanes because most
+// lanes of a wave are in the middle of a walk, and every execution costs the wave the same whatever the lane count.
+// With XCHG the waves of a workgroup take roles: wave 0 SHADES, the others WALK.  A walker parks the lanes whose walk
+// just ended (pending SHADE or SCATTER) in pool R and refills them from pool W with walks waiting to start; the shader
+// takes walk results from R by the wavefront, runs the short phases on full waves, parks the walks they start in W.  A
+// record is the lane's whole state (60 dwords: path, pixel, random stream, ray, walk result, light sample); walks in
+// progress never move (their stack stays where it is).  A slot is claimed under the workgroup's lock (a few dozen cycles:
+// one state word per slot, one lane per slot), copied outside it and published by its state word, so waves do not queue
+// behind each other's copies.  Nothing ever waits: a wave that cannot trade (lock taken, pool full or empty, the other
+// role gone) carries on with the per-wave schedule, which remains complete on its own.
+constexpr uint32_t kXchgRecWords = 60;        // 15 x 16 bytes; = 4 * 15: sixteen lanes of a b128 pass hit sixteen bank groups
+constexpr uint32_t kXchgFineSlots = 64;       // records per pool: one lane looks after one slot
+constexpr uint32_t kXchgFineHdr = 8 + 2 * 64; // lock, counts, alive flags; one state word per slot of W and of R
+#ifndef RT_XCHG_SHADERS
+#define RT_XCHG_SHADERS 1
+#endif
+constexpr uint32_t kXchgShaderWaves = RT_XCHG_SHADERS; // waves of a workgroup (the first ones) that shade
+enum : uint32_t { XS_EMPTY = 0, XS_FULL = 1, XS_BUSY = 2 };
 
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F, bool XCHG = false>
-__global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
+__global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F, FINE, XCHG>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
                                                      float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
                                                      uint32_t *__restrict__ work_counter, uint32_t *__restrict__ stack_ovf)
 {
@@ -225,8 +245,12 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	// exchange pool (XCHG): [lock, parked paths, parked pixels, pad] [paths: word k of slot s at k * slots + s] [pixels likewise]
 	uint32_t *pool = lds + (((uint32_t)(SM.region - lds) + (blockDim.x >> 6) * (P.stack_cap * kStackStride) + 3u) & ~3u);
 	if (XCHG) {
-		if (threadIdx.x < 4u)
+		if (FINE) { // [lock, records in W, records in R, shaders alive, walkers alive, -, -, -] [state of W's slots] [of R's]
+			if (threadIdx.x < kXchgFineHdr)
+				pool[threadIdx.x] = threadIdx.x == 3u ? kXchgShaderWaves : (threadIdx.x == 4u ? (blockDim.x >> 6) - kXchgShaderWaves : 0u);
+		} else if (threadIdx.x < 4u) {
 			pool[threadIdx.x] = 0u;
+		}
 		__syncthreads();
 	}
 
@@ -290,6 +314,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			ph = PH_NODE;
 			return;
 		}
+		if (XCHG) { // the walk may start in another wave: start_walk below, after the exchange
+			ph = PH_WALK;
+			return;
+		}
 		if (root_box_misses(S, ray)) {
 			node = kRefDone;
 			ph = shadow ? PH_SCATTER : PH_SHADE;
@@ -297,6 +325,19 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			ph = PH_NARROW; // a zero direction component or a non-finite origin: only the two-child walk is exact for it
 		} else {
 			node = S.root4_ref; // the fine schedule walks the wide tree (the host selects it only when one exists)
+			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
+		}
+	};
+	// PH_WALK -> the first step of the walk (what begin_walk does at once without the exchange)
+	auto start_walk = [&]() {
+		sp = 0;
+		if (root_box_misses(S, ray)) {
+			node = kRefDone;
+			ph = any_hit ? PH_SCATTER : PH_SHADE;
+		} else if (S.narrow_only != 0u || !ray_is_regular(ray)) {
+			ph = PH_NARROW;
+		} else {
+			node = S.root4_ref;
 			ph = ref_is_leaf(node) ? PH_LEAF : PH_NODE;
 		}
 	};
@@ -659,6 +700,171 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 		}
 	};
 
+	// ---- XCHG, fine schedule: the lane's whole state as one record, and the trade itself (see kXchgRecWords above) ----
+	auto record_store = [&](uint32_t *rec) {
+		uint4 *d = reinterpret_cast<uint4 *>(rec);
+		const uint32_t fl = (hit.has_uv ? 1u : 0u) | (hit.out ? 2u : 0u) | (primary ? 4u : 0u) | (any_hit ? 8u : 0u) | (PL.have_shadow ? 16u : 0u) |
+		                    (PL.shadow_is_sky ? 32u : 0u);
+		d[0] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
+		d[1] = make_uint4(__float_as_uint(thr.x), __float_as_uint(thr.y), __float_as_uint(thr.z), __float_as_uint(outp.x));
+		d[2] = make_uint4(__float_as_uint(outp.y), __float_as_uint(outp.z), __float_as_uint(wo.x), __float_as_uint(wo.y));
+		d[3] = make_uint4(__float_as_uint(wo.z), __float_as_uint(hit.t), __float_as_uint(hit.point.x), __float_as_uint(hit.point.y));
+		d[4] = make_uint4(__float_as_uint(hit.point.z), __float_as_uint(hit.error.x), __float_as_uint(hit.error.y), __float_as_uint(hit.error.z));
+		d[5] = make_uint4(__float_as_uint(hit.normal.x), __float_as_uint(hit.normal.y), __float_as_uint(hit.normal.z), __float_as_uint(hit.uvx));
+		d[6] = make_uint4(__float_as_uint(hit.uvy), fl, mat, depth);
+		d[7] = make_uint4(ray_count, __float_as_uint(mean.x), __float_as_uint(mean.y), __float_as_uint(mean.z));
+		d[8] = make_uint4(sample_local, out_index, pixel_index, px);
+		d[9] = make_uint4(py, chunk_begin, chunk_n, (uint32_t)ph);
+		d[10] = make_uint4(__float_as_uint(ray.o.x), __float_as_uint(ray.o.y), __float_as_uint(ray.o.z), __float_as_uint(ray.d.x));
+		d[11] = make_uint4(__float_as_uint(ray.d.y), __float_as_uint(ray.d.z), __float_as_uint(ray.inv.x), __float_as_uint(ray.inv.y));
+		d[12] = make_uint4(__float_as_uint(ray.inv.z), __float_as_uint(ray.shear.x), __float_as_uint(ray.shear.y), __float_as_uint(ray.shear.z));
+		d[13] = make_uint4(__float_as_uint(best_t), best_prim, __float_as_uint(PL.t_limit), PL.skip);
+		d[14] = make_uint4(__float_as_uint(PL.l_wi.x), __float_as_uint(PL.l_wi.y), __float_as_uint(PL.l_wi.z), __float_as_uint(PL.pdf_multiplier));
+	};
+	auto record_load = [&](const uint32_t *rec) {
+		const uint4 *d = reinterpret_cast<const uint4 *>(rec);
+		const uint4 a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3], a4 = d[4], a5 = d[5], a6 = d[6], a7 = d[7], a8 = d[8], a9 = d[9];
+		const uint4 a10 = d[10], a11 = d[11], a12 = d[12], a13 = d[13], a14 = d[14];
+		rng.s0 = a0.x; rng.s1 = a0.y; rng.s2 = a0.z; rng.s3 = a0.w;
+		thr = v3(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z));
+		outp = v3(__uint_as_float(a1.w), __uint_as_float(a2.x), __uint_as_float(a2.y));
+		wo = v3(__uint_as_float(a2.z), __uint_as_float(a2.w), __uint_as_float(a3.x));
+		hit.t = __uint_as_float(a3.y);
+		hit.point = v3(__uint_as_float(a3.z), __uint_as_float(a3.w), __uint_as_float(a4.x));
+		hit.error = v3(__uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
+		hit.normal = v3(__uint_as_float(a5.x), __uint_as_float(a5.y), __uint_as_float(a5.z));
+		hit.uvx = __uint_as_float(a5.w);
+		hit.uvy = __uint_as_float(a6.x);
+		hit.has_uv = (a6.y & 1u) != 0u; hit.out = (a6.y & 2u) != 0u; primary = (a6.y & 4u) != 0u;
+		any_hit = (a6.y & 8u) != 0u; PL.have_shadow = (a6.y & 16u) != 0u; PL.shadow_is_sky = (a6.y & 32u) != 0u;
+		mat = a6.z; depth = a6.w;
+		ray_count = a7.x;
+		mean = v3(__uint_as_float(a7.y), __uint_as_float(a7.z), __uint_as_float(a7.w));
+		sample_local = a8.x; out_index = a8.y; pixel_index = a8.z; px = a8.w;
+		py = a9.x; chunk_begin = a9.y; chunk_n = a9.z; ph = (int)a9.w;
+		ray.o = v3(__uint_as_float(a10.x), __uint_as_float(a10.y), __uint_as_float(a10.z));
+		ray.d = v3(__uint_as_float(a10.w), __uint_as_float(a11.x), __uint_as_float(a11.y));
+		ray.inv = v3(__uint_as_float(a11.z), __uint_as_float(a11.w), __uint_as_float(a12.x));
+		ray.shear = v3(__uint_as_float(a12.y), __uint_as_float(a12.z), __uint_as_float(a12.w));
+		best_t = __uint_as_float(a13.x); best_prim = a13.y; PL.t_limit = __uint_as_float(a13.z); PL.skip = a13.w;
+		PL.l_wi = v3(__uint_as_float(a14.x), __uint_as_float(a14.y), __uint_as_float(a14.z));
+		PL.pdf_multiplier = __uint_as_float(a14.w);
+		node = kRefDone; // (a record never holds a walk in progress)
+		sp = 0;
+	};
+	const bool xchg_shader = wave < kXchgShaderWaves;
+	auto xchg_try_lock = [&]() -> bool {
+		uint32_t got = 0u;
+		if (lane == 0u) {
+			uint32_t expect = 0u;
+			got = __hip_atomic_compare_exchange_strong(&pool[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+		}
+		if (__shfl(got, 0) == 0u)
+			return false;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		return true;
+	};
+	auto xchg_unlock = [&]() {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (lane == 0u)
+			__hip_atomic_store(&pool[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	auto exchange_fine = [&]() {
+		const uint32_t slots = kXchgFineSlots;
+		// the shader gives walks to start (W) and takes walk results (R); a walker the other way round
+		const uint32_t iG = xchg_shader ? 1u : 2u, iT = xchg_shader ? 2u : 1u, iOther = xchg_shader ? 4u : 3u;
+		uint32_t *stG = pool + 8 + (xchg_shader ? 0u : 64u), *stT = pool + 8 + (xchg_shader ? 64u : 0u);
+		uint32_t *xmap = pool + kXchgFineHdr + wave * 64u; // this wave's scratch: slot of the q-th claim
+		uint32_t *recW = pool + kXchgFineHdr + (blockDim.x >> 6) * 64u, *recR = recW + slots * kXchgRecWords;
+		uint32_t *recG = xchg_shader ? recW : recR, *recT = xchg_shader ? recR : recW;
+		const unsigned long long mGive = xchg_shader ? __ballot(ph == PH_WALK) : __ballot(ph == PH_SHADE || ph == PH_SCATTER);
+		const unsigned long long mFree = __ballot(ph == PH_NEED_PIXEL || ph == PH_DONE);
+		const uint32_t n_give_want = (uint32_t)__popcll(mGive), n_free = (uint32_t)__popcll(mFree);
+		const uint32_t peekG = __hip_atomic_load(&pool[iG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const uint32_t peekT = __hip_atomic_load(&pool[iT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const uint32_t other = __hip_atomic_load(&pool[iOther], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		// A trade is a SWAP, one record given for one taken: lanes vacated by a gift without a return would fetch fresh
+		// pixels, and the extra states would fill both pools until nothing moves.  Gifts without a return only prime the
+		// pools (while the two together hold less than one pool's worth); lanes with nothing take without giving.
+		const bool may_swap = other != 0u && n_give_want >= kXchgMinLanes && peekG < slots && peekT != 0u;
+		const bool may_prime = other != 0u && n_give_want >= kXchgMinLanes && peekG + peekT + kXchgMinLanes <= slots;
+		const bool may_take = peekT != 0u && n_free != 0u;
+		if (!may_swap && !may_prime && !may_take)
+			return;
+		if (!xchg_try_lock())
+			return;
+		// ---- under the lock: claim slots (state words only) ----
+		const uint32_t sG = lane < slots ? stG[lane] : (uint32_t)XS_BUSY, sT = lane < slots ? stT[lane] : (uint32_t)XS_BUSY;
+		const unsigned long long m_empty = __ballot(sG == XS_EMPTY), m_full = __ballot(sT == XS_FULL);
+		const uint32_t other_now = pool[iOther], parked = pool[1] + pool[2];
+		const uint32_t n_can_give = (other_now != 0u && n_give_want >= kXchgMinLanes) ? min(n_give_want, (uint32_t)__popcll(m_empty)) : 0u;
+		const uint32_t n_swap = min(n_can_give, (uint32_t)__popcll(m_full));
+		const uint32_t n_prime = min(n_can_give - n_swap, parked < slots ? slots - parked : 0u);
+		const uint32_t n_give = n_swap + n_prime;
+		const uint32_t n_take = n_swap + min((uint32_t)__popcll(m_full) - n_swap, n_free);
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const uint32_t qE = (uint32_t)__popcll(m_empty & below), qF = (uint32_t)__popcll(m_full & below);
+		const bool claimE = (m_empty >> lane & 1ull) != 0ull && qE < n_give, claimF = (m_full >> lane & 1ull) != 0ull && qF < n_take;
+		if (claimE)
+			stG[lane] = XS_BUSY;
+		if (claimF)
+			stT[lane] = XS_BUSY;
+		if (lane == 0u) {
+			pool[iG] = pool[iG] + n_give;
+			pool[iT] = pool[iT] - n_take;
+		}
+		xchg_unlock();
+		// ---- outside it: move the records ----
+		const uint32_t rG = (uint32_t)__popcll(mGive & below);
+		const bool giver = (mGive >> lane & 1ull) != 0ull && rG < n_give;
+		if (claimE)
+			xmap[qE] = lane;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		uint32_t slotG = 0u;
+		if (giver) {
+			slotG = xmap[rG];
+			record_store(recG + slotG * kXchgRecWords);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (giver)
+			__hip_atomic_store(&stG[slotG], (uint32_t)XS_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__builtin_amdgcn_wave_barrier();
+		if (claimF)
+			xmap[qF] = lane;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// who takes: the lanes that just gave their state away first, then the lanes that had nothing
+		const bool is_free = (mFree >> lane & 1ull) != 0ull;
+		const uint32_t rT = (giver && rG < n_swap) ? rG : (is_free ? n_swap + (uint32_t)__popcll(mFree & below) : 0xFFFFFFFFu);
+		const bool taker = rT < n_take;
+		uint32_t slotT = 0u;
+		if (taker) {
+			slotT = xmap[rT];
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			record_load(recT + slotT * kXchgRecWords);
+		} else if (giver) {
+			ph = PH_NEED_PIXEL; // the lane is vacant (its record primed the pool)
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (taker)
+			__hip_atomic_store(&stT[slotT], (uint32_t)XS_EMPTY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	};
+	// the wave has nothing left: it may go once the pool it takes from is empty -- and says so under the lock, so that
+	// the other role stops giving to it (nothing can be parked for a wave that has left)
+	auto xchg_try_exit = [&]() -> bool {
+		if (!xchg_try_lock())
+			return false;
+		const uint32_t *stT = pool + 8 + (xchg_shader ? 64u : 0u);
+		const bool empty = __ballot(lane < kXchgFineSlots && stT[lane] != XS_EMPTY) == 0ull;
+		if (empty && lane == 0u)
+			pool[xchg_shader ? 3u : 4u] -= 1u;
+		xchg_unlock();
+		return empty;
+	};
+
 	// XCHG -- trade with the workgroup's pool before the wave votes.  Between iterations of the coarse MIS schedule a
 	// lane is in exactly one of four states: PH_GEN (a pixel between samples), PH_LIGHT (a path between bounces),
 	// PH_NEED_PIXEL, PH_DONE.  The wave picks the super-phase it could run FULLER after a trade -- BOUNCE by swapping its
@@ -805,6 +1011,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 	for (;;) {
 		if (XCHG && METHOD == 1 && !FINE)
 			exchange();
+		if (XCHG && FINE) {
+			exchange_fine();
+			// walks start where they are now -- except in the shading wave, which holds the ones it could not give away
+			// until the walkers have made room (they do not depend on it for that), or starts them itself once no walker is left
+			if (ph == PH_WALK && (!xchg_shader || __hip_atomic_load(&pool[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u))
+				start_walk();
+		}
 		// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
 		// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
 		// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and
@@ -868,12 +1081,14 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 			uint32_t best_n = 0;
 #pragma unroll
 			for (int k = PH_COUNT - 1; k >= 0; --k) {
+				if (XCHG && xchg_shader)
+					break; // the shading wave has nothing to keep flowing: it runs its fullest phase (below)
 				if (k != PH_NODE && run < 0 && cnt[k] >= (k == PH_NARROW ? 1u : (k == PH_LEAF ? kDrainLanes : kDrainLanesHeavy))) {
 					run = k;
 					best_n = cnt[k];
 				}
 			}
-			if (run < 0 && cnt[PH_NODE] > 0u) {
+			if (run < 0 && cnt[PH_NODE] > 0u && !(XCHG && xchg_shader)) {
 				run = PH_NODE;
 				best_n = cnt[PH_NODE];
 			}
@@ -887,9 +1102,18 @@ __global__ __launch_bounds__((KernelShape<F, FINE>::block), (KernelShape<F, FINE
 				}
 			}
 			if (run < 0) {
-				if (__ballot(ph == PH_NEED_PIXEL) == 0ull)
-					break; // every lane is PH_DONE
-				continue;  // only edge-tile padding was handed out: ask again
+				if (XCHG && __ballot(ph == PH_WALK) != 0ull) { // (the shading wave, holding walks for the walkers)
+					__builtin_amdgcn_s_sleep(4);
+					continue;
+				}
+				if (__ballot(ph == PH_NEED_PIXEL) == 0ull) { // every lane is PH_DONE
+					if (XCHG && !xchg_try_exit()) {
+						__builtin_amdgcn_s_sleep(4);
+						continue; // records are still parked for this wave (or the lock was taken): look again
+					}
+					break;
+				}
+				continue; // only edge-tile padding was handed out: ask again
 			}
 #ifdef RT_STATS
 			if (lane == 0u) {
@@ -1358,8 +1582,10 @@ extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
 }
 #endif
 
-uint32_t render_block_threads(int feature_set, bool fine)
+uint32_t render_block_threads(int feature_set, bool fine, bool xchg)
 {
+	if (fine && xchg)
+		return 512u; // KernelShape<F, true, true>::block
 	if (feature_set == 0)
 		return (uint32_t)KernelShape<Feat<false, false, false, false>>::block;
 	if (feature_set == 1)
@@ -1397,9 +1623,13 @@ using FeatSimple = Feat<true, true, false, false>;    // + triangles and emissiv
 
 template <class F> static render_fn pick_render_f(int method, bool prune, bool fine, bool sky_lds, bool xchg)
 {
-	if (xchg) { // built for the coarse exhaustive MIS kernels (configs 2 and 3)
+	if (xchg) { // built for the coarse exhaustive MIS kernels (configs 2 and 3) and for the fine schedule
 		if (method == 1 && !prune && !fine)
 			return sky_lds ? render_kernel<1, false, false, true, F, true> : render_kernel<1, false, false, false, F, true>;
+		if (fine && method == 0)
+			return render_kernel<0, true, true, false, F, true>;
+		if (fine && method == 1)
+			return sky_lds ? render_kernel<1, true, true, true, F, true> : render_kernel<1, true, true, false, F, true>;
 		return nullptr;
 	}
 #define RT_PICK(M, P, G, L) \
@@ -1432,10 +1662,12 @@ static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, in
 		return pick_render_f<FeatSimple>(method, prune, fine, sky_lds, xchg);
 	return pick_render_f<FeatFull>(method, prune, fine, sky_lds, xchg);
 }
-bool render_exchange_available(int method, bool prune, bool fine, int feature_set) { (void)feature_set; return method == 1 && !prune && !fine; }
+bool render_exchange_available(int method, bool prune, bool fine, int feature_set) { (void)feature_set; return fine || (method == 1 && !prune); }
 // LDS of a pool of `slots` parked paths + pixels (incl. the header and the slack of aligning it to 16 bytes)
 size_t render_exchange_lds_bytes(uint32_t slots) { return (size_t)(4u + 4u + (kXchgBStride + kXchgPStride) * slots) * sizeof(uint32_t); }
 uint32_t render_exchange_max_slots() { return kXchgMaxSlots; }
+// ... and of the two record pools of the fine schedule (+ state words, + one scratch row per wave)
+size_t render_exchange_fine_lds_bytes(uint32_t waves_per_block) { return (size_t)(4u + kXchgFineHdr + waves_per_block * 64u + 2u * kXchgFineSlots * kXchgRecWords) * sizeof(uint32_t); }
 
 hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg)
 {
@@ -1445,7 +1677,7 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess)
 		return e;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set, fine), lds_bytes);
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set, fine, xchg), lds_bytes);
 }
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
@@ -1455,7 +1687,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
 		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter,
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter,
 	                   stack_ovf);
 	return hipGetLastError();
 }
