@@ -757,7 +757,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		// pick_render (rt_render.hip) folds these: naive never stages the sky, fine implies pruned
 		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s%s>", (int)o->render_method, prune ? "true" : "false",
 		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set],
-		              xchg ? ", true" : "");
+		              xchg ? ", true" : ", false"); // the name rocprofv3 prints
 	}
 	if (P.stack_ovf_depth != 0u) { // grown on first use only (like the sample_split scratch: not capturable on that call)
 		const size_t need = (size_t)n_blocks * block_threads * P.stack_ovf_depth;

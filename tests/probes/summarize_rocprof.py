@@ -31,7 +31,8 @@ workload = sys.argv[2] if len(sys.argv) > 2 else read("workload.txt", "rtweekend
 w = bench.WORKLOADS[workload]
 samples_per_launch = (w["width"] * w["height"] // (w["shard"][1] if "shard" in w else 1)) * w["spp"]
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+# (a tag that was profiled twice keeps both runs' files under gpurun_out/: the newest run is the one that counts)
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     wr = csv.DictWriter(f, fieldnames=rows[0].keys())
@@ -46,7 +47,7 @@ launches = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         per = collections.defaultdict(float)
         ids = set()
         info = {}
