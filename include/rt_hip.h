@@ -385,6 +385,15 @@ int rt_check_hit(rt_scene *scene, const rt_ray_desc *rays, uint64_t n_rays, rt_h
 int rt_check_hit_index(rt_scene *scene, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n_rays,
                        rt_hit_record *out);
 
+/* ---- self-test of the kernels' arithmetic.  The render kernels compute `a / b`, `sqrtf` and the elementary functions
+ * of include/rt_detmath.h through shorter instruction sequences wherever the operands make the omitted steps the identity
+ * (raytracing-rust_amd/csrc/rt_lean.h).  This call runs both forms side by side ON `device` over 262 144 x n_per_thread random
+ * and edge-case operands per class and counts results whose bits differ (NaN == NaN): classes 0 division, 1 division with a
+ * zero / infinite / NaN numerator, 2 reciprocal, 3 vector / scalar, 4 square root, 5 sin + cos, 6 acos, 7 atan2,
+ * 8 Ray::new (rt_core/src/ray.rs:13-46).  Every count must be zero. ---- */
+#define RT_SELFTEST_LEAN_CLASSES 9
+int rt_selftest_lean(int device, uint64_t n_per_thread, uint64_t seed, uint64_t mismatches[RT_SELFTEST_LEAN_CLASSES]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,7 @@ EXPORTED_SYMBOLS = [
     "rt_render_rgb8",
     "rt_check_hit",
     "rt_check_hit_index",
+    "rt_selftest_lean",
 ]
 
 

@@ -39,6 +39,7 @@ hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, c
 hipError_t launch_trace_queue(int waves, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream, const DevScene &S, const void *rays, uint32_t n, void *out,
                               uint32_t *counter, unsigned long long *steps, uint32_t cap, uint32_t ovf_depth, uint32_t *ovf);
 #endif
+hipError_t launch_selftest_lean(hipStream_t stream, uint32_t blocks, uint64_t n_per_thread, uint64_t seed, unsigned long long *mismatches);
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
 } // namespace rt
@@ -1286,6 +1287,27 @@ int rt_check_hit_index(rt_scene *s, const rt_ray_desc *rays, const uint64_t *obj
 	if (!object_index)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	return check_common(s, rays, object_index, n_rays, out);
+}
+
+int rt_selftest_lean(int device, uint64_t n_per_thread, uint64_t seed, uint64_t mismatches[RT_SELFTEST_LEAN_CLASSES])
+{
+	if (!mismatches || n_per_thread == 0 || n_per_thread > (1ull << 20))
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments (n_per_thread in [1, 2^20])");
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+		return fail(RT_ERR_NO_DEVICE, "no such HIP device");
+	HIP_TRY(hipSetDevice(device));
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), RT_SELFTEST_LEAN_CLASSES * sizeof(unsigned long long)));
+	hipError_t e = hipMemset(d, 0, RT_SELFTEST_LEAN_CLASSES * sizeof(unsigned long long));
+	if (e == hipSuccess)
+		e = launch_selftest_lean(nullptr, 1024u, n_per_thread, seed, d);
+	if (e == hipSuccess)
+		e = hipMemcpy(mismatches, d, RT_SELFTEST_LEAN_CLASSES * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess)
+		return hip_fail(e, "selftest");
+	return RT_OK;
 }
 
 } // extern "C"

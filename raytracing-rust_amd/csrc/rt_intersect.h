@@ -16,6 +16,7 @@
 #pragma once
 
 #include "rt_types.h"
+#include "rt_lean.h"
 
 namespace rt {
 
@@ -24,11 +25,36 @@ struct Ray {
 };
 
 // Ray::new  ray.rs:13-46 (time is carried nowhere: it is never read on the render path)
+// Six to nine divisions and a square root per ray.  When every component of the direction is non-zero with magnitude in
+// [2^-60, 2^20] and the squared length lies in [2^-40, 2^40] (every ray a render produces, bar the exactly axis-parallel
+// ones) all operands below are tame in the sense of rt_lean.h -- length in [2^-20, 2^20], normalised components in
+// [2^-81, 1], numerators 1 or such components -- so the short forms return the bits of the plain operators; any other
+// direction takes the plain operators.
 template <class F> __device__ __forceinline__ Ray ray_new(V3 origin, V3 direction)
 {
 	Ray r;
-	direction = direction / mag(direction);
 	r.o = origin;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_LEAN)
+	const float m2 = dot(direction, direction);
+	const float smallest = fminf(fminf(fabsf(direction.x), fabsf(direction.y)), fabsf(direction.z));
+	if (__builtin_expect(smallest >= 0x1p-60f && m2 >= 0x1p-40f && m2 <= 0x1p40f, 1)) {
+		direction = lean_div3(direction, lean_sqrt(m2));
+		r.d = direction;
+		r.inv = v3(lean_inv(direction.x), lean_inv(direction.y), lean_inv(direction.z));
+		if (F::tri) {
+			const float ax = fabsf(direction.x), ay = fabsf(direction.y), az = fabsf(direction.z);
+			const bool swap = (ax > ay && ax > az) || (ay > az);
+			const float sx = swap ? direction.z : direction.x;
+			const float sz = swap ? direction.x : direction.z;
+			const float rz = lean_rcp_refined(sz);
+			r.shear = v3(lean_div_core(-sx, sz, rz), lean_div_core(-direction.y, sz, rz), lean_div_core(1.0f, sz, rz));
+		} else {
+			r.shear = v3s(0.0f);
+		}
+		return r;
+	}
+#endif
+	direction = direction / mag(direction);
 	r.d = direction;
 	r.inv = v3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
 	if (F::tri) {

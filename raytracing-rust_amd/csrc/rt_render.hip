@@ -1571,6 +1571,112 @@ hipError_t launch_trace_queue(int waves, uint32_t n_blocks, size_t lds_bytes, hi
 }
 #endif
 
+// ---- rt_selftest_lean: the short arithmetic forms of rt_lean.h against the plain operators / rt_detmath.h, on the device.
+// Operand classes: 0 lean_div, 1 lean_div_fix (numerator may be zero / inf / NaN), 2 lean_inv, 3 lean_div3 (shared reciprocal),
+// 4 lean_sqrt, 5 lean_sincos, 6 lean_acos_dev, 7 lean_atan2, 8 ray_new (fast path and fallback against the plain operators).
+// mismatches[k] counts results whose BITS differ (two NaNs count as equal). ----
+__device__ __forceinline__ bool same_f32(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+__device__ __forceinline__ float tame_from_bits(uint32_t u, int lo_exp, int hi_exp) // random sign and mantissa, exponent in [lo_exp, hi_exp]
+{
+	const uint32_t span = (uint32_t)(hi_exp - lo_exp + 1);
+	const uint32_t e = (uint32_t)(127 + lo_exp) + ((u >> 23) & 0xFFu) % span;
+	return __uint_as_float((u & 0x807FFFFFu) | (e << 23));
+}
+__device__ __noinline__ Ray ray_new_plain(V3 origin, V3 direction) // the plain operators, kept out of line so nothing is shared with the short form
+{
+	Ray r;
+	direction = direction / mag(direction);
+	r.o = origin;
+	r.d = direction;
+	r.inv = v3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+	const float ax = fabsf(direction.x), ay = fabsf(direction.y), az = fabsf(direction.z);
+	const bool swap = (ax > ay && ax > az) || (ay > az);
+	const float sx = swap ? direction.z : direction.x;
+	const float sz = swap ? direction.x : direction.z;
+	r.shear = v3(-sx / sz, -direction.y / sz, 1.0f / sz);
+	return r;
+}
+__global__ __launch_bounds__(256) void selftest_lean_kernel(uint64_t n_per_thread, uint64_t seed, unsigned long long *__restrict__ mismatches)
+{
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	rt_rng rng;
+	rt_rng_seed(&rng, seed, tid, 0x5E1F7E57ull);
+	unsigned long long bad[9] = {};
+	for (uint64_t it = 0; it < n_per_thread; ++it) {
+		const uint32_t u0 = rt_rng_u32(&rng), u1 = rt_rng_u32(&rng), u2 = rt_rng_u32(&rng), u3 = rt_rng_u32(&rng);
+		// tame operands at the EDGES of what the call sites guarantee as well as in the middle
+		const float d = tame_from_bits(u0, -81, 41), n = tame_from_bits(u1, -81, 41);
+		if (fabsf(n) <= fabsf(d) * 0x1p95f && fabsf(d) <= fabsf(n) * 0x1p120f) {
+			bad[0] += !same_f32(lean_div(n, d), n / d);
+			bad[1] += !same_f32(lean_div_fix(n, d), n / d);
+		}
+		const uint32_t pick = u2 & 7u; // special numerators for the fix-up form
+		const float ns = pick == 0u ? 0.0f : (pick == 1u ? -0.0f : (pick == 2u ? INFINITY : (pick == 3u ? -INFINITY : (pick == 4u ? __uint_as_float(0x7FC00000u) : n))));
+		if (pick < 5u)
+			bad[1] += !same_f32(lean_div_fix(ns, d), ns / d);
+		bad[2] += !same_f32(lean_inv(d), 1.0f / d);
+		{
+			const V3 v = v3(tame_from_bits(u1, -60, 20), tame_from_bits(u2, -60, 20), tame_from_bits(u3, -60, 20));
+			const float dd = tame_from_bits(u0, -20, 20);
+			const V3 a = lean_div3(v, dd), b = v / dd;
+			bad[3] += !(same_f32(a.x, b.x) && same_f32(a.y, b.y) && same_f32(a.z, b.z));
+			const V3 vz = v3((u3 & 1u) ? 0.0f : v.x, (u3 & 2u) ? -0.0f : v.y, v.z);
+			const V3 af = lean_div3_fix(vz, dd), bf = vz / dd;
+			bad[3] += !(same_f32(af.x, bf.x) && same_f32(af.y, bf.y) && same_f32(af.z, bf.z));
+		}
+		{
+			// square roots: the whole stated domain -- zero, [2^-96, inf], NaN, negatives -- and squares near exact roots
+			const uint32_t k = u3 & 15u;
+			float x = fabsf(tame_from_bits(u0, -96, 127));
+			if (k == 0u) x = 0.0f; else if (k == 1u) x = -0.0f; else if (k == 2u) x = INFINITY; else if (k == 3u) x = -fabsf(n);
+			else if (k == 4u) { const float r = fabsf(tame_from_bits(u1, -40, 40)); x = r * r; }
+			else if (k == 5u) x = 1.0f - (float)(u1 >> 8) * 5.9604644775390625e-08f; // 1 - r, the Lambert sampler's argument
+			else if (k == 6u) x = __uint_as_float(0x0F800000u + (u1 & 0xFFu));          // just above 2^-96
+			bad[4] += !same_f32(lean_sqrt(x), sqrtf(x));
+		}
+		{
+			const float r = (float)(u0 >> 8) * 5.9604644775390625e-08f;
+			const float ang = (u1 & 1u) ? 2.0f * kPi * r : ((u1 & 2u) ? kPi * r * (1.0f + 0x1p-20f) : (float)(int32_t)(u2 >> 9) * r - 4194304.0f * r);
+			float s_, c_;
+			lean_sincos(ang, s_, c_);
+			bad[5] += !(same_f32(s_, rt_sinf(ang)) && same_f32(c_, rt_cosf(ang)));
+		}
+		{
+			const uint32_t k = u3 & 7u;
+			float x = 2.0f * ((float)(u0 >> 8) * 5.9604644775390625e-08f) - 1.0f;
+			if (k == 0u) x = tame_from_bits(u0, -30, 1); else if (k == 1u) x = (u1 & 1u) ? 1.0f : -1.0f; else if (k == 2u) x = __uint_as_float(0x3F000000u + (u1 & 3u) - 1u);
+			else if (k == 3u) x = __uint_as_float(0x7FC00000u);
+			bad[6] += !same_f32(lean_acos_dev(x), rt_acosf(x));
+		}
+		{
+			const uint32_t k = u3 >> 28;
+			float y = tame_from_bits(u0, -30, 30), x = tame_from_bits(u1, -30, 30);
+			if (k == 0u) y = 0.0f; else if (k == 1u) x = -0.0f; else if (k == 2u) { x = 0.0f; y = -0.0f; } else if (k == 3u) y = (u2 & 1u) ? x : -x;
+			else if (k == 4u) x = INFINITY; else if (k == 5u) { x = -INFINITY; y = INFINITY; } else if (k == 6u) y = __uint_as_float(0x7FC00000u);
+			else if (k == 7u) { x = __uint_as_float(u0); y = __uint_as_float(u1); }
+			bad[7] += !same_f32(lean_atan2(y, x), rt_atan2f(y, x));
+		}
+		{
+			const uint32_t k = u3 & 15u;
+			V3 dir = v3(tame_from_bits(u0, -8, 8), tame_from_bits(u1, -8, 8), tame_from_bits(u2, -8, 8));
+			if (k == 0u) dir.x = 0.0f; else if (k == 1u) dir = v3(tame_from_bits(u0, -62, -58), tame_from_bits(u1, -8, 8), tame_from_bits(u2, -22, 21));
+			else if (k == 2u) dir = v3(tame_from_bits(u0, -70, 70), tame_from_bits(u1, -70, 70), tame_from_bits(u2, -70, 70));
+			else if (k == 3u) dir.y = -0.0f;
+			const Ray a = ray_new<FeatFull>(v3s(0.0f), dir), b = ray_new_plain(v3s(0.0f), dir);
+			bad[8] += !(same_f32(a.d.x, b.d.x) && same_f32(a.d.y, b.d.y) && same_f32(a.d.z, b.d.z) && same_f32(a.inv.x, b.inv.x) && same_f32(a.inv.y, b.inv.y) &&
+			            same_f32(a.inv.z, b.inv.z) && same_f32(a.shear.x, b.shear.x) && same_f32(a.shear.y, b.shear.y) && same_f32(a.shear.z, b.shear.z));
+		}
+	}
+	for (int k = 0; k < 9; ++k)
+		if (bad[k])
+			atomicAdd(&mismatches[k], bad[k]);
+}
+hipError_t launch_selftest_lean(hipStream_t stream, uint32_t blocks, uint64_t n_per_thread, uint64_t seed, unsigned long long *mismatches)
+{
+	hipLaunchKernelGGL(selftest_lean_kernel, dim3(blocks), dim3(256), 0, stream, n_per_thread, seed, mismatches);
+	return hipGetLastError();
+}
+
 // ---- launchers (called from rt_api.cpp) ----
 #ifdef RT_STATS
 extern "C" int rt_debug_stats(unsigned long long *out16, int reset)

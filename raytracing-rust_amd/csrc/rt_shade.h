@@ -12,6 +12,16 @@
 
 namespace rt {
 
+// sqrtf for arguments that are provably zero, negative, NaN or >= 2^-96 (each use says why): the short form of rt_lean.h
+__device__ __forceinline__ float sqrt_unit_(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_LEAN)
+	return lean_sqrt(x);
+#else
+	return sqrtf(x);
+#endif
+}
+
 // ---- utility/mod.rs ----
 __device__ __forceinline__ float next_float(float f) // :51-65
 {
@@ -143,8 +153,8 @@ template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &
 		return sign > 0.0f ? v3(t.c1[0], t.c1[1], t.c1[2]) : v3(t.c2[0], t.c2[1], t.c2[2]);
 	}
 	if (type == 2) { // ImageTexture :251-262
-		const float phi = rt_atan2f(direction.y, direction.x) + kPi;
-		const float theta = rt_acosf(direction.z);
+		const float phi = lean_atan2(direction.y, direction.x) + kPi;
+		const float theta = lean_acos_dev(direction.z);
 		const float uvx = phi / (2.0f * kPi);
 		const float uvy = theta / kPi;
 		const uint32_t x_pixel = f32_as_index((float)t.dim_x * uvx);
@@ -218,11 +228,12 @@ __device__ __forceinline__ bool sky_can_sample(const DevScene &S) { return (S.sk
 // Sky::pdf  sky.rs:43-60 with Distribution2D::pdf distributions.rs:105-110
 __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, V3 wi)
 {
-	const float sin_theta = sqrtf(1.0f - wi.z * wi.z);
+	// 1 - z * z is zero, negative, NaN or >= 2^-24: inside the range of the short square root (rt_lean.h)
+	const float sin_theta = sqrt_unit_(1.0f - wi.z * wi.z);
 	if (sin_theta <= 0.0f)
 		return 0.0f;
-	const float theta = rt_acosf(wi.z);
-	float phi = rt_atan2f(wi.y, wi.x);
+	const float theta = lean_acos_dev(wi.z);
+	float phi = lean_atan2(wi.y, wi.x);
 	if (phi < 0.0f)
 		phi += 2.0f * kPi;
 	const float u = phi / (2.0f * kPi);
@@ -250,17 +261,23 @@ __device__ __forceinline__ V3 sky_sample(const DevScene &S, const SkyTables &T, 
 	const float v = next_float((float)sv + rt_rng_f32(&rng)) / (float)ry;
 	const float phi = u * 2.0f * kPi;
 	const float theta = v * kPi;
-	const float st = rt_sinf(theta), ct = rt_cosf(theta), sp = rt_sinf(phi), cp = rt_cosf(phi);
+	// u and v lie in (0, 1 + 2^-20]: angles far inside lean_sincos's domain
+	float st, ct, sp, cp;
+	lean_sincos(theta, st, ct);
+	lean_sincos(phi, sp, cp);
 	return v3(st * cp, st * sp, ct); // Vec3::from_spherical  vec.rs:155-163
 }
 
 // ---- statistics/bxdfs ----
 __device__ __forceinline__ V3 lambertian_sample(V3 normal, rt_rng &rng) // lambertian.rs:5-18
 {
-	const float cos_theta = sqrtf(1.0f - rt_rng_f32(&rng));
-	const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+	// 1 - r with r in [0, 1 - 2^-24] is >= 2^-24; 1 - c * c with c in [2^-12, 1] is zero or >= 2^-24 (rt_lean.h)
+	const float cos_theta = sqrt_unit_(1.0f - rt_rng_f32(&rng));
+	const float sin_theta = sqrt_unit_(1.0f - cos_theta * cos_theta);
 	const float phi = 2.0f * kPi * rt_rng_f32(&rng);
-	const V3 local = v3(rt_cosf(phi) * sin_theta, rt_sinf(phi) * sin_theta, cos_theta);
+	float sin_phi, cos_phi;
+	lean_sincos(phi, sin_phi, cos_phi);
+	const V3 local = v3(cos_phi * sin_theta, sin_phi * sin_theta, cos_theta);
 	const Coord c = coord_from_z(normal);
 	return to_coord(c, local);
 }
@@ -307,8 +324,10 @@ __device__ inline V3 tr_sample_vndf(float a_x, float a_y, V3 incoming, rt_rng &r
 	const V3 basis_three = cross(vh, basis_two);
 	const float r = sqrtf(rt_rng_f32(&rng));
 	const float phi = kTau * rt_rng_f32(&rng);
-	const float tx = r * rt_cosf(phi);
-	float ty = r * rt_sinf(phi);
+	float sin_phi, cos_phi;
+	lean_sincos(phi, sin_phi, cos_phi);
+	const float tx = r * cos_phi;
+	float ty = r * sin_phi;
 	const float s = 0.5f * (1.0f + vh.z);
 	ty = (1.0f - s) * sqrtf(1.0f - tx * tx) + s * ty;
 	const V3 hh = tx * basis_two + ty * basis_three + sqrtf(fmax_(1.0f - tx * tx - ty * ty, 0.0f)) * vh;
@@ -491,7 +510,9 @@ template <class F> __device__ inline V3 prim_sample_visible_from_point(const Pri
 			const float z = 1.0f - 2.0f * rt_rng_f32(&rng);
 			const float a = sqrtf(fmax_(1.0f - z * z, 0.0f));
 			const float b = 2.0f * kPi * rt_rng_f32(&rng);
-			point = center + radius * v3(a * rt_cosf(b), a * rt_sinf(b), z);
+			float sin_b, cos_b;
+			lean_sincos(b, sin_b, cos_b);
+			point = center + radius * v3(a * cos_b, a * sin_b, z);
 		} else {
 			const float distance = sqrtf(distance_sq);
 			const float sin_theta_max_sq = radius * radius / distance_sq;
@@ -504,7 +525,9 @@ template <class F> __device__ inline V3 prim_sample_visible_from_point(const Pri
 			const float cos_alpha = (distance_sq + radius * radius - ds * ds) / (2.0f * distance * radius);
 			const float sin_alpha = sqrtf(fmax_(1.0f - cos_alpha * cos_alpha, 0.0f));
 			const Coord cs = coord_from_z(normalised(in_point - center));
-			const V3 vec = to_coord(cs, v3(sin_alpha * rt_cosf(phi), sin_alpha * rt_sinf(phi), cos_alpha));
+			float sin_phi, cos_phi;
+			lean_sincos(phi, sin_phi, cos_phi);
+			const V3 vec = to_coord(cs, v3(sin_alpha * cos_phi, sin_alpha * sin_phi, cos_alpha));
 			point = center + radius * vec;
 		}
 		return normalised(point - in_point);

@@ -65,6 +65,14 @@ def device_count():
     return int(lib().rt_device_count())
 
 
+def selftest_lean(device=0, n_per_thread=64, seed=1):
+    """rt_selftest_lean: mismatch counts per operand class between the kernels' short arithmetic forms
+    (csrc/rt_lean.h) and the plain IEEE operators / rt_detmath.h, evaluated on the GPU.  All must be zero."""
+    out = (C.c_uint64 * 9)()
+    _check(lib().rt_selftest_lean(C.c_int(device), C.c_uint64(n_per_thread), C.c_uint64(seed), out))
+    return [int(x) for x in out]
+
+
 def camera_new(origin, lookat, vup, fov, aspect_ratio, aperture, focus_dist):
     """SimpleCamera::new (camera.rs:20-54)."""
     cam = abi.Camera()
