@@ -265,6 +265,8 @@ vec3 ora_lambertian_sample(vec3 incoming, vec3 normal, ora_ctx *ctx);           
 float ora_lambertian_pdf(vec3 incoming, vec3 outgoing, vec3 normal);                  /* :20-22 */
 vec3 ora_tr_vndf_sample(float alpha, vec3 incoming, vec3 normal, ora_ctx *ctx);       /* trowbridge_reitz_vndf.rs:37-42 */
 float ora_tr_vndf_pdf(float alpha, vec3 incoming, vec3 outgoing, vec3 normal);        /* :44-54 */
+vec3 ora_tr_vndf_sample_h(float alpha, vec3 incoming, ora_ctx *ctx);                   /* :17-19 isotropic::sample_vndf */
+float ora_tr_vndf_h(float alpha, vec3 h, vec3 incoming);                               /* :9-15  isotropic::vndf */
 
 /* ---- integrators (ora_render.c) ---- */
 vec3 ora_naive_get_colour(const ora_scene *s, ora_ray *ray, uint32_t max_depth, uint32_t rr_threshold, uint64_t *ray_count, ora_ctx *ctx); /* integrators/mod.rs:22-78 */

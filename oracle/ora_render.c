@@ -810,6 +810,7 @@ int ora_sample_directions(const ora_scene *scene, int32_t which, const float inc
 			}
 			d = ora_prim_sample_visible_from_point(scene, &scene->primitives[prim_index], incoming, &ctx);
 			break;
+		case 5: d = ora_tr_vndf_sample_h(alpha, incoming, &ctx); break; /* half vectors, local frame */
 		default:
 			ora_ctx_free(&ctx);
 			return fail(RT_ERR_INVALID_ARGUMENT, "unknown sampler");
@@ -841,6 +842,7 @@ int ora_eval_pdfs(const ora_scene *scene, int32_t which, const float incoming_[3
 			}
 			out[i] = ora_sky_pdf(scene, d, &ctx);
 			break;
+		case 5: out[i] = ora_tr_vndf_h(alpha, d, incoming); break;
 		default:
 			ora_ctx_free(&ctx);
 			return fail(RT_ERR_INVALID_ARGUMENT, "unknown pdf");

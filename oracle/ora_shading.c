@@ -397,6 +397,10 @@ static vec3 tr_sample_vndf(float a_x, float a_y, vec3 incoming, ora_ctx *ctx)
 
 	return v3_normalised(v3(a_x * h_hemisphere.x, a_y * h_hemisphere.y, f_max(h_hemisphere.z, 0.0f)));
 }
+/* the two halves of the reference's `isotropic_h` test (trowbridge_reitz_vndf.rs:157-165): isotropic::sample_vndf and
+ * isotropic::vndf on half vectors, local frame */
+vec3 ora_tr_vndf_sample_h(float alpha, vec3 incoming, ora_ctx *ctx) { return tr_sample_vndf(alpha, alpha, incoming, ctx); }
+float ora_tr_vndf_h(float alpha, vec3 h, vec3 incoming) { return tr_vndf(alpha, h, incoming); }
 /* trowbridge_reitz_vndf.rs:37-42  isotropic::sample */
 vec3 ora_tr_vndf_sample(float alpha, vec3 incoming, vec3 normal, ora_ctx *ctx)
 {

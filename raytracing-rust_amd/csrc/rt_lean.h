@@ -22,7 +22,7 @@
 //     `a / b` computes.  Every use states why its operands are tame, or tests it (one or two compares per ray) and takes
 //     the plain operator otherwise.  rt_selftest_lean (rt_api.cpp) runs both forms side by side ON THE DEVICE over random
 //     and edge-case operands; tests/test_gpu_parity.py::test_lean_arithmetic_matches_the_ieee_operators asserts zero
-//     mismatches, and every parity test compares frames that went through them with the oracle's plain C.
+//     mismatches, and every parity test compares frames that went through them with the CPU checker's plain C.
 #pragma once
 
 #include "rt_vec.h"

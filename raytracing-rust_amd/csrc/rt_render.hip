@@ -178,15 +178,51 @@ constexpr uint32_t kXchgFineHdr = 8 + 2 * 64; // lock, counts, alive flags; one 
 constexpr uint32_t kXchgShaderWaves = RT_XCHG_SHADERS; // waves of a workgroup (the first ones) that shade
 enum : uint32_t { XS_EMPTY = 0, XS_FULL = 1, XS_BUSY = 2 };
 
+// Everything a render launch is told, as ONE by-value kernel argument, so that it sits at offset 0 of the kernarg segment and
+// the kernel can read any field from there with a scalar load WHERE IT IS USED.  Taken as ordinary by-value parameters, the
+// compiler loads all of them in the prologue and keeps them in SGPRs for the life of the persistent loop: 170 dwords of
+// arguments against 100 usable SGPRs meant 65 (spheres-only) to 105 (simple variants) of them lived in VGPR lanes and
+// came back through v_readlane / v_writelane inside the loop.  Fields a phase needs on every execution and that are
+// few (max_depth, rr_threshold, the scene's tables) stay ordinary values; the camera, the seed, the sample window and
+// the tile geometry (used once per sample or once per pixel) are re-read through kargs() below.
+struct RenderArgs {
+	DevScene S;
+	DevCamera cam;
+	DevRenderParams P;
+	float *out;
+	unsigned long long *rays_shot;
+	uint32_t *work_counter;
+	uint32_t *stack_ovf;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) RenderArgs *KArgs; // the kernarg segment is constant memory: s_load
+#else
+typedef const RenderArgs *KArgs; // (host pass: the kernel body is only parsed)
+#endif
+
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F, bool XCHG = false>
-__global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F, FINE, XCHG>::waves_per_simd)) void render_kernel(const DevScene S_global, const DevCamera cam, const DevRenderParams P,
-                                                     float *__restrict__ out, unsigned long long *__restrict__ rays_shot,
-                                                     uint32_t *__restrict__ work_counter, uint32_t *__restrict__ stack_ovf)
+__global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F, FINE, XCHG>::waves_per_simd)) void render_kernel(const RenderArgs args_by_value)
 {
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 
+	(void)args_by_value; // read through the kernarg pointer only
+#if defined(__HIP_DEVICE_COMPILE__)
+	const KArgs K = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+	// a pointer the optimiser cannot see through: loads made through it stay where they are written (no hoisting out of the loop)
+	auto kargs = [&]() -> KArgs {
+		KArgs k = K;
+		asm volatile("" : "+s"(k));
+		return k;
+	};
+#else
+	const KArgs K = &args_by_value;
+	auto kargs = [&]() -> KArgs { return K; };
+#endif
+	const DevScene S_global = K->S;
+	const DevRenderParams P = K->P; // (fields used only through kargs() are never loaded from this copy)
+	uint32_t *const stack_ovf = K->stack_ovf;
 	DevScene S = S_global;
 
 	// ---- stage the sky CDF rows + marginal CDF into LDS ----
@@ -257,12 +293,6 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		__syncthreads();
 	}
 
-	const uint64_t seed = ((uint64_t)P.seed_hi << 32) | P.seed_lo;
-	const uint64_t sample_begin = ((uint64_t)P.sample_begin_hi << 32) | P.sample_begin_lo;
-	const V3 cam_o = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
-	const V3 cam_ll = v3(cam.lower_left[0], cam.lower_left[1], cam.lower_left[2]);
-	const V3 cam_h = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
-	const V3 cam_v = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
 	const bool sky_samplable = sky_can_sample(S);
 
 	// ---- per-lane state (registers) ----
@@ -363,6 +393,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		rays_total += ray_count;
 		sample_local += 1;
 		if (sample_local == chunk_n) {
+			float *const out = kargs()->out;
 			out[3u * (size_t)out_index + 0u] = mean.x;
 			out[3u * (size_t)out_index + 1u] = mean.y;
 			out[3u * (size_t)out_index + 2u] = mean.z;
@@ -374,9 +405,16 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 
 	// GEN -- new sample: the pixel loop body of sample_image, random_sampler.rs:50-61
 	auto do_gen = [&]() {
+		const KArgs k = kargs(); // seed, sample window, image size and camera: scalar loads here, once per sample
+		const uint64_t seed = ((uint64_t)k->P.seed_hi << 32) | k->P.seed_lo;
+		const uint64_t sample_begin = ((uint64_t)k->P.sample_begin_hi << 32) | k->P.sample_begin_lo;
+		const V3 cam_o = v3(k->cam.origin[0], k->cam.origin[1], k->cam.origin[2]);
+		const V3 cam_ll = v3(k->cam.lower_left[0], k->cam.lower_left[1], k->cam.lower_left[2]);
+		const V3 cam_h = v3(k->cam.horizontal[0], k->cam.horizontal[1], k->cam.horizontal[2]);
+		const V3 cam_v = v3(k->cam.vertical[0], k->cam.vertical[1], k->cam.vertical[2]);
 		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + chunk_begin + sample_local);
-		const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(P.width - 1u);
-		const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(P.height - 1u);
+		const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(k->P.width - 1u);
+		const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(k->P.height - 1u);
 		// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
 		ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
 		(void)rt_rng_f32(&rng);
@@ -1011,63 +1049,67 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
+	auto acquire = [&]() {
+	// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
+	// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
+	// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and
+	// with sample_split there can be tens of millions of items).  All of this is wave-uniform. ----
+	{
+		const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
+		if (need != 0ull) {
+			const KArgs k = kargs(); // the tile geometry is needed once per pixel: read it here, not in the prologue
+			const DevRenderParams P = k->P;
+			const uint32_t n = (uint32_t)__popcll(need);
+			const uint32_t avail = wq_end - wq_next;
+			uint32_t base = wq_end;
+			if (avail < n) {
+				const int leader = __ffsll((long long)need) - 1;
+				uint32_t claimed = 0;
+				if ((int)lane == leader)
+					claimed = atomicAdd(k->work_counter, kClaim);
+				base = __shfl(claimed, leader);
+			}
+			if (ph == PH_NEED_PIXEL) {
+				const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+				const uint32_t w = r < avail ? wq_next + r : base + (r - avail);
+				if (w >= P.n_items) {
+					ph = PH_DONE;
+				} else if (work_to_pixel(P, P.sample_split > 1u ? w % P.n_work : w, px, py)) {
+					pixel_index = py * P.width + px;
+					if (P.sample_split > 1u) {
+						// sample_split (rt_hip.h): this item is chunk c of its pixel; its mean goes to the
+						// partial buffer (chunk-major) and combine_chunks_kernel folds the chunks in order
+						const uint32_t c = w / P.n_work;
+						chunk_begin = (uint32_t)(((uint64_t)c * P.spp) / P.sample_split);
+						chunk_n = (uint32_t)(((uint64_t)(c + 1u) * P.spp) / P.sample_split) - chunk_begin;
+						out_index = w;
+					} else {
+						out_index = P.shard_layout ? w : pixel_index;
+					}
+					sample_local = 0;
+					mean = v3s(0.0f);
+					ph = PH_GEN;
+				} // else: padding of an edge tile; ask again next iteration
+			}
+			if (avail < n) { // the leftovers went first, the rest came from the new block
+				wq_next = base + (n - avail);
+				wq_end = base + kClaim;
+			} else {
+				wq_next += n;
+			}
+		}
+	}
+	};
+	if constexpr (FINE)
 	for (;;) {
-		if (XCHG && METHOD == 1 && !FINE)
-			exchange();
-		if (XCHG && FINE) {
+		if (XCHG) {
 			exchange_fine();
 			// walks start where they are now -- except in the shading wave, which holds the ones it could not give away
 			// until the walkers have made room (they do not depend on it for that), or starts them itself once no walker is left
 			if (ph == PH_WALK && (!xchg_shader || __hip_atomic_load(&pool[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u))
 				start_walk();
 		}
-		// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
-		// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
-		// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and
-		// with sample_split there can be tens of millions of items).  All of this is wave-uniform. ----
-		{
-			const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
-			if (need != 0ull) {
-				const uint32_t n = (uint32_t)__popcll(need);
-				const uint32_t avail = wq_end - wq_next;
-				uint32_t base = wq_end;
-				if (avail < n) {
-					const int leader = __ffsll((long long)need) - 1;
-					uint32_t claimed = 0;
-					if ((int)lane == leader)
-						claimed = atomicAdd(work_counter, kClaim);
-					base = __shfl(claimed, leader);
-				}
-				if (ph == PH_NEED_PIXEL) {
-					const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-					const uint32_t w = r < avail ? wq_next + r : base + (r - avail);
-					if (w >= P.n_items) {
-						ph = PH_DONE;
-					} else if (work_to_pixel(P, P.sample_split > 1u ? w % P.n_work : w, px, py)) {
-						pixel_index = py * P.width + px;
-						if (P.sample_split > 1u) {
-							// sample_split (rt_hip.h): this item is chunk c of its pixel; its mean goes to the
-							// partial buffer (chunk-major) and combine_chunks_kernel folds the chunks in order
-							const uint32_t c = w / P.n_work;
-							chunk_begin = (uint32_t)(((uint64_t)c * P.spp) / P.sample_split);
-							chunk_n = (uint32_t)(((uint64_t)(c + 1u) * P.spp) / P.sample_split) - chunk_begin;
-							out_index = w;
-						} else {
-							out_index = P.shard_layout ? w : pixel_index;
-						}
-						sample_local = 0;
-						mean = v3s(0.0f);
-						ph = PH_GEN;
-					} // else: padding of an edge tile; ask again next iteration
-				}
-				if (avail < n) { // the leftovers went first, the rest came from the new block
-					wq_next = base + (n - avail);
-					wq_end = base + kClaim;
-				} else {
-					wq_next += n;
-				}
-			}
-		}
+		acquire();
 		if (FINE) {
 			// ---- big trees: every step is its own phase; run the one most lanes wait for
 			// (ties: the later pipeline stage) ----
@@ -1163,87 +1205,94 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				st_mark = now_;
 			}
 #endif
-		} else {
+		}
+	}
+
+	// ---- tiny trees (a walk is a handful of steps): the coarse schedule, a loop of its own with ONE exit and ONE back edge.
+	// (As one `for (;;)` shared with the fine schedule, leaving through `break` / `continue` in nested branches, the
+	// structurised loop copied the whole loop-carried lane state -- about 45 registers -- twice per iteration.) ----
+	if constexpr (!FINE) {
+		bool alive = true; // wave-uniform
+		while (alive) {
+			if (XCHG && METHOD == 1)
+				exchange();
+			acquire();
 			// ---- tiny trees (a walk is a handful of steps): two super-phases.
 			//   TRACE = GEN + closest walk + SHADE     LIGHT = LIGHT + shadow walk + SCATTER
 			// About half of all SHADE outcomes end the sample; those lanes regenerate and stay in
 			// TRACE while continuing paths pile up for LIGHT, which runs once enough lanes wait. ----
 			const uint32_t n_light = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
 			const uint32_t n_trace = (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
-			if (n_light + n_trace == 0u) {
-				if (__ballot(ph == PH_NEED_PIXEL) == 0ull) {
-					if (XCHG && METHOD == 1) { // parked work left?  (a later push comes from a wave that is still alive and will drain it itself)
-						if (__hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
-						    __hip_atomic_load(&pool[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u)
-							continue;
+			if (n_light + n_trace != 0u) {
+				const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
+	#ifdef RT_STATS
+				if (lane == 0u) {
+					if (!run_light) {
+						st_iters[0] += 1; st_active[0] += n_trace;
+						st_gen += (unsigned long long)__popcll(__ballot(ph == PH_GEN));
+					} else {
+						st_iters[1] += 1; st_active[1] += n_light;
 					}
-					break;
 				}
-				continue;
-			}
-			const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
-#ifdef RT_STATS
-			if (lane == 0u) {
+	#endif
+				RT_SECTION(0); // vote + work acquisition
 				if (!run_light) {
-					st_iters[0] += 1; st_active[0] += n_trace;
-					st_gen += (unsigned long long)__popcll(__ballot(ph == PH_GEN));
+					if (ph == PH_GEN)
+						do_gen();
+					RT_SECTION(1);
+					walk_closest_pending();
+					RT_SECTION(2);
+					if (ph == PH_SHADE)
+						do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
+					RT_SECTION(3);
 				} else {
-					st_iters[1] += 1; st_active[1] += n_light;
+					LightCtx L; // loop-local: see LightCtx above
+					L.l_wi = v3s(0.0f);
+					L.pdf_multiplier = 1.0f;
+					L.t_limit = 0.0f;
+					L.skip = kNoPrim;
+					L.have_shadow = L.shadow_is_sky = false;
+					Ray sray;
+					sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
+					if (ph == PH_LIGHT)
+						do_light(L, sray);
+					RT_SECTION(4);
+					walk_shadow_pending(L, sray);
+					RT_SECTION(5);
+					if (ph == PH_SCATTER)
+						do_scatter(L, sray);
+					RT_SECTION(6);
+	#if RT_PQ_SPLIT
+					// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
+					// the other super-phase only ever holds primary lanes and neither arm runs half empty
+					walk_closest_pending();
+					RT_SECTION(7);
+					if (ph == PH_SHADE)
+						do_shade(std::integral_constant<int, 2>{});
+					RT_SECTION(8);
+	#endif
 				}
-			}
-#endif
-			RT_SECTION(0); // vote + work acquisition
-			if (!run_light) {
-				if (ph == PH_GEN)
-					do_gen();
-				RT_SECTION(1);
-				walk_closest_pending();
-				RT_SECTION(2);
-				if (ph == PH_SHADE)
-					do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
-				RT_SECTION(3);
+	#if RT_PQ_SPLIT
+				if (METHOD == 1) {
+					// With the two super-phases above no walk is ever pending at the end of an iteration: the ray and
+					// the walk state are dead here.  Saying so keeps them out of the loop-carried registers.
+					ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
+					best_t = 0.0f;
+					best_prim = kNoPrim;
+					node = kRefDone;
+					sp = 0;
+					any_hit = false;
+				}
+	#endif
 			} else {
-				LightCtx L; // loop-local: see LightCtx above
-				L.l_wi = v3s(0.0f);
-				L.pdf_multiplier = 1.0f;
-				L.t_limit = 0.0f;
-				L.skip = kNoPrim;
-				L.have_shadow = L.shadow_is_sky = false;
-				Ray sray;
-				sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
-				if (ph == PH_LIGHT)
-					do_light(L, sray);
-				RT_SECTION(4);
-				walk_shadow_pending(L, sray);
-				RT_SECTION(5);
-				if (ph == PH_SCATTER)
-					do_scatter(L, sray);
-				RT_SECTION(6);
-#if RT_PQ_SPLIT
-				// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
-				// the other super-phase only ever holds primary lanes and neither arm runs half empty
-				walk_closest_pending();
-				RT_SECTION(7);
-				if (ph == PH_SHADE)
-					do_shade(std::integral_constant<int, 2>{});
-				RT_SECTION(8);
-#endif
+				// nothing to run: lanes waiting for a pixel (only edge-tile padding was handed out) ask again; otherwise the wave is done
+				alive = __ballot(ph == PH_NEED_PIXEL) != 0ull;
+				if (XCHG && METHOD == 1) // parked work left?  (a later push comes from a wave that is still alive and will drain it itself)
+					alive = alive || __hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
+					        __hip_atomic_load(&pool[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
 			}
-#if RT_PQ_SPLIT
-			if (METHOD == 1) {
-				// With the two super-phases above no walk is ever pending at the end of an iteration: the ray and
-				// the walk state are dead here.  Saying so keeps them out of the loop-carried registers.
-				ray.o = ray.d = ray.inv = ray.shear = v3s(0.0f);
-				best_t = 0.0f;
-				best_prim = kNoPrim;
-				node = kRefDone;
-				sp = 0;
-				any_hit = false;
-			}
-#endif
 		}
 	}
-
 #ifdef RT_STATS
 	atomicAdd(&g_stats[20], st_lane_nodes); // lane-level node steps and primitive tests of the fine schedule
 	atomicAdd(&g_stats[21], st_lane_prims);
@@ -1263,6 +1312,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	}
 #endif
 	// ---- SamplerProgress.rays_shot: wave reduction, one atomic per wave ----
+	unsigned long long *const rays_shot = K->rays_shot;
 	if (rays_shot != nullptr) {
 		for (int off = 32; off > 0; off >>= 1)
 			rays_total += __shfl_down(rays_total, off);
@@ -1724,7 +1774,7 @@ size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_
 	return words * sizeof(uint32_t);
 }
 
-typedef void (*render_fn)(const DevScene, const DevCamera, const DevRenderParams, float *, unsigned long long *, uint32_t *, uint32_t *);
+typedef void (*render_fn)(const RenderArgs);
 
 // feature sets the render kernel is instantiated for (rt_api.cpp picks the smallest that covers the scene)
 using FeatSpheres = Feat<false, false, false, false>; // spheres, Lambertian/Emit, Solid/Lerp, sky is the only light (rtweekend1)
@@ -1732,6 +1782,12 @@ using FeatSimple = Feat<true, true, false, false>;    // + triangles and emissiv
 
 template <class F> static render_fn pick_render_f(int method, bool prune, bool fine, bool sky_lds, bool xchg)
 {
+#ifdef RT_ONLY_HEADLINE // ISA studies (tests/probes/isa_headline.sh): instantiate the kernels of BASELINE configs 2 and 3 only
+	if constexpr (!(F::cmat || F::ctex))
+		if (method == 1 && !prune && !fine && sky_lds && !xchg)
+			return render_kernel<1, false, false, true, F>;
+	return nullptr;
+#else
 	if (xchg) { // built for the coarse exhaustive MIS kernels (configs 2 and 3) and for the fine schedule
 		if (method == 1 && !prune && !fine)
 			return sky_lds ? render_kernel<1, false, false, true, F, true> : render_kernel<1, false, false, false, F, true>;
@@ -1756,6 +1812,7 @@ template <class F> static render_fn pick_render_f(int method, bool prune, bool f
 	RT_PICK(1, true, true, true)
 #undef RT_PICK
 	return nullptr;
+#endif
 }
 
 // feature_set: 0 spheres-only, 1 simple, 2 full
@@ -1796,8 +1853,15 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
 		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, S, cam, P, out, rays_shot, work_counter,
-	                   stack_ovf);
+	RenderArgs A;
+	A.S = S;
+	A.cam = cam;
+	A.P = P;
+	A.out = out;
+	A.rays_shot = rays_shot;
+	A.work_counter = work_counter;
+	A.stack_ovf = stack_ovf;
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, A);
 	return hipGetLastError();
 }
 

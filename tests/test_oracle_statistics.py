@@ -46,8 +46,8 @@ def chi2_ok(counts, probs, n):
     return stats.chi2.sf(stat, len(e) - 1)
 
 
-def run_case(sample_fn, pdf_fn, n=300000, integrates_to=1.0, tol=2e-2):
-    probs = integrate_pdf(pdf_fn)
+def run_case(sample_fn, pdf_fn, n=300000, integrates_to=1.0, tol=2e-2, sub=12):
+    probs = integrate_pdf(pdf_fn, sub)
     assert abs(probs.sum() - integrates_to) < tol, probs.sum()
     counts = bin_directions(sample_fn(n))
     p = chi2_ok(counts, probs / probs.sum(), n)
@@ -70,6 +70,16 @@ def test_trowbridge_reitz_vndf(O, alpha):  # trowbridge_reitz_vndf.rs:150-219
     inc = np.array([0.4, 0.2, 0.89]); inc /= np.linalg.norm(inc)
     run_case(lambda n: O.sample_directions_noscene(1, n, seed=13, incoming=inc, alpha=alpha),
              lambda d: O.eval_pdfs_noscene(1, d, incoming=inc, alpha=alpha))
+
+
+@pytest.mark.parametrize("alpha", [0.1, 0.3, 0.7])
+def test_trowbridge_reitz_vndf_half_vectors(O, alpha):  # `isotropic_h`, trowbridge_reitz_vndf.rs:157-165
+    """isotropic::vndf(alpha, h, incoming) as the density of the half vectors isotropic::sample_vndf draws
+    (local frame; incoming = -generate_wi(): a direction of the upper hemisphere, spherical_sampling.rs:237-242)"""
+    inc = np.array([-0.35, 0.45, 0.82]); inc /= np.linalg.norm(inc)
+    # (the density of half vectors is D-shaped: at alpha 0.1 its peak is narrower than a 12 x 12 quadrature cell)
+    run_case(lambda n: O.sample_directions_noscene(5, n, seed=19, incoming=inc, alpha=alpha),
+             lambda d: O.eval_pdfs_noscene(5, d, incoming=inc, alpha=alpha), sub=96 if alpha < 0.2 else 24)
 
 
 def test_trowbridge_reitz_vndf_rotated_normal(O):
