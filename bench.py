@@ -86,6 +86,22 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def useful_valu_share(kernel):
+    """1 - (v_mov / v_cndmask / v_readlane / v_writelane share of the kernel's VALU instructions), from the committed static
+    census of the build's assembly (profiles/valu_census.json, written by tests/probes/isa_census.py --write and keyed by the
+    hash of the kernel sources): the roofline fraction counts every issued VALU instruction, this says how many of them
+    compute.  Static (per instruction of the binary, cold paths included), not a dynamic count."""
+    p = os.path.join(ROOT, "profiles", "valu_census.json")
+    if not os.path.exists(p):
+        return {"useful_valu_share": None}
+    census = json.load(open(p))
+    k = census.get("kernels", {}).get(kernel)
+    if not k:
+        return {"useful_valu_share": None}
+    return {"useful_valu_share": k["useful_valu_share"], "valu_census": {x: k[x] for x in ("valu", "moves", "v_mov", "v_cndmask", "lane_spill", "div", "salu")},
+            "valu_census_measured_on_this_build": census.get("source_hash") == source_hash()}
+
+
 def load_workload(pkg, name):
     """(scene description, camera parameters) of a workload"""
     w = WORKLOADS[name]
@@ -203,16 +219,20 @@ def walk_stats_child(name):
 
 
 def walk_stats(name):
+    """(statistics, error): the untimed pass of the -DRT_STATS diagnostic build in a child process.  A failure there (library
+    missing, child crash, timeout, unparsable output) is REPORTED -- in the JSON line and on stderr -- never retried, never silent."""
     lib = os.path.join(ROOT, "raytracing-rust_amd", "librt_hip_stats.so")
     if not os.path.exists(lib):
-        return None
+        return None, {"error": "librt_hip_stats.so not built (make -C raytracing-rust_amd/csrc)"}
     env = dict(os.environ, RT_HIP_LIB=lib)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--walk-stats-child", name], env=env, capture_output=True,
                            text=True, timeout=900)
-        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
-    except Exception:
-        return None
+        if r.returncode != 0:
+            return None, {"error": "walk-statistics child failed", "returncode": r.returncode, "stderr_tail": r.stderr[-800:]}
+        return json.loads(r.stdout.strip().splitlines()[-1]), None
+    except Exception as e:  # timeout, bad JSON
+        return None, {"error": f"{type(e).__name__}: {e}"}
 
 
 def spawn_ranks(n):
@@ -251,6 +271,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-walk-stats", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["cfg1"], default="rtweekend1")
+    ap.add_argument("--abi-devices", default=None,
+                    help="comma-separated device list, e.g. 0,1,2,3: ONE process renders through rt_scene_create_multi (the C ABI's own "
+                         "multi-GPU path: tiles t %% n, in-process gather into the first device) instead of one rank per GPU")
     ap.add_argument("--walk-stats-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.walk_stats_child:
@@ -309,7 +332,11 @@ def main():
 
     scene_desc, camera_params = load_workload(pkg, name)
     t0 = time.time()
-    scene = hb.HipScene(scene_desc, device=local_rank)  # BVH build + upload: not part of the timed region
+    abi_devices = [int(x) for x in args.abi_devices.split(",")] if args.abi_devices else None
+    if abi_devices and (world > 1 or "shard" in w):
+        raise SystemExit("--abi-devices is the one-process multi-GPU path: use it with --gpus 1 and an unsharded workload")
+    # BVH build + upload: not part of the timed region
+    scene = hb.HipScene(scene_desc, devices=abi_devices) if abi_devices else hb.HipScene(scene_desc, device=local_rank)
     build_s = time.time() - t0
     cam = hb.camera_new(**camera_params)
 
@@ -325,12 +352,16 @@ def main():
     while world > 1 and (WIDTH * HEIGHT // world) * split < 32 * lanes and split < SPP // 16:
         split *= 2
     opts.sample_split = split
+    if abi_devices and len(abi_devices) > 1:
+        opts.sample_split = 0  # the library picks the split for its device list (same rule, rt_hip.h)
     if "shard" in w:  # one rank's shard of a larger job: render it packed, nothing to gather
         shard_index, shard_count = w["shard"]
     else:
         shard_index, shard_count = rank, world
     sopts = D.shard_opts(opts, shard_index, shard_count)
-    gather = D.ShardGather(opts, rank, world, comm_device) if "shard" not in w else None
+    gather = D.ShardGather(opts, rank, world, comm_device) if ("shard" not in w and not abi_devices) else None
+    if abi_devices:
+        sopts = opts  # whole frame, RT_LAYOUT_FRAME: the scene shards over its devices by itself
     n_shard_floats = hb.output_floats(sopts)
     shard = torch.zeros(n_shard_floats // 3, 3, dtype=torch.float32, device=device) if gather is None else gather.new_shard_buffer()
     frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=comm_device) if (rank == 0 and gather is not None) else None
@@ -367,6 +398,16 @@ def main():
     elapsed = float(t.item())
     rays = D.reduce_rays(d_rays.clone().to(comm_device), world)
     launch = scene.last_launch_info()
+    # SURVEY 8(d) defines the metric on rt_render: the frame delivered to a HOST buffer (+ one D2H of W x H x 12 bytes and the
+    # host synchronisation).  Timed here next to the device-resident figure above, on a few untimed-for-`value` steps.
+    host_frame_ms = None
+    if world == 1:
+        scene.render(cam, sopts)
+        n_host = max(2, min(5, args.steps))
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            scene.render(cam, sopts)
+        host_frame_ms = (time.perf_counter() - t0) / n_host * 1e3
 
     if rank == 0:
         samples_per_step = (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else 1)) * SPP
@@ -384,7 +425,10 @@ def main():
         roof = {"bound": w["bound"], "kernel": launch["kernel"], "kernel_ms": k_ms,
                 "launch": {k: launch[k] for k in ("block_threads", "n_blocks", "blocks_per_cu", "waves_per_simd", "lds_bytes", "n_cus",
                                                   "sky_in_lds", "scene_in_lds")},
-                "traffic": counters.get("hbm_bytes_per_launch") if world == 1 else None,
+                # HBM bytes per launch (PMC, measured at N = 1).  N > 1: a rank writes 1/N of the frame and reads the same scene,
+                # so its share of the one-GPU figure is the estimate printed, and the note says that it is one
+                "traffic": (counters.get("hbm_bytes_per_launch") / world) if counters.get("hbm_bytes_per_launch") else None,
+                "traffic_note": None if world == 1 else f"per rank: the one-GPU PMC figure / {world} (frame writes dominate; not re-measured at N = {world})",
                 "counters_source": counters.get("source"), "counters_measured_on_this_build": current}
         if w["bound"] == "valu_issue":
             vps = counters.get("valu_wave_instructions_per_sample")
@@ -392,6 +436,7 @@ def main():
             roof.update({"achieved": achieved / 1e9 if achieved else None, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G VALU wave-instructions/s",
                          "frac": min(achieved / VALU_ISSUE_PEAK, 1.0) if achieved else None,
                          "valu_wave_instructions_per_sample": vps, "lane_utilisation": counters.get("valu_lane_utilisation"),
+                         **useful_valu_share(launch["kernel"]),
                          "note": "scene and sky tables live in SGPRs/LDS; HBM sees 12 B/pixel per frame (traffic), so the bound is VALU "
                                  "issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"})
         elif w["bound"] == "l2_request_rate":
@@ -411,7 +456,10 @@ def main():
                                  "rate of an L2-resident set (115 G/s), 57 G/s beyond L2 (profiles/r01d_random_fetch_microbench.txt)"})
         ws = None
         if world == 1 and not args.no_walk_stats:
-            ws = walk_stats(name)
+            ws, ws_error = walk_stats(name)
+            if ws_error:
+                roof["walk_stats_error"] = ws_error
+                print(f"bench.py: walk statistics unavailable: {ws_error}", file=sys.stderr, flush=True)
         if ws and "primary_phase_lanes" in ws:
             # NS1: how full the waves are at the level cross-lane compaction could fix (paths that wait for the other
             # super-phase).  The VALU lane utilisation above is lower because lanes also idle INSIDE a phase (branches of
@@ -446,7 +494,7 @@ def main():
             "metric": "Msamples/s on rtweekend1.ssml 1920x1080x1024spp" if name == "rtweekend1" else f"Msamples/s on {name} {WIDTH}x{HEIGHT}x{SPP}spp",
             "value": value,
             "unit": "Msamples/s",
-            "n_gpus": world,
+            "n_gpus": world if not abi_devices else len(set(abi_devices)),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -457,8 +505,15 @@ def main():
             "data": "synthetic" if not rehearsal else f"synthetic -- REHEARSAL: {world} ranks share one GPU over gloo; not a measurement",
             "config": {"workload": f"{w['label']} {WIDTH}x{HEIGHT} {SPP}spp MIS max_depth=50 rr=3 seed={w['seed']} ({w['config']})",
                        "parallelism": (f"{world} ranks (one per GPU), 8x8 tiles interleaved t % {world}, replicated BVH, one RCCL gather per frame"
-                                       if world > 1 else ("1 GPU" + (f", shard {w['shard'][0]} of {w['shard'][1]}" if "shard" in w else ""))),
-                       "sample_split": split,
+                                       if world > 1 else
+                                       (f"one process, devices {abi_devices} through rt_scene_create_multi (tiles t % {len(abi_devices)}, in-process gather)"
+                                        if abi_devices else ("1 GPU" + (f", shard {w['shard'][0]} of {w['shard'][1]}" if "shard" in w else "")))),
+                       "sample_split": split if not abi_devices else "library (rt_scene_create_multi)",
+                       "ms_per_step_host_frame": host_frame_ms,
+                       "value_host_frame": (samples_per_step / host_frame_ms / 1e3) if host_frame_ms else None,
+                       "host_frame_note": "rt_render: the same step with the frame copied to a host buffer (SURVEY 8(d)'s wall-seconds of rt_render); "
+                                          "`value` is the HBM-resident rate the bench contract asks for",
+                       "abi_devices": abi_devices,
                        "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
                        "scene_build_s": build_s},
             "roofline": roof,

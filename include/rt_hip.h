@@ -182,7 +182,8 @@ typedef struct rt_render_opts {
 	uint32_t tile_width;    /* shard granularity in pixels; 0 = default (8) */
 	uint32_t tile_height;   /* 0 = default (8) */
 	int32_t output_layout;  /* rt_output_layout */
-	/* 0 or 1 (default): a pixel's passes are folded strictly in pass order, `mean += (pass-mean)/i`,
+	/* 1 (default; 0 means the same on a single-device scene and "automatic" on a multi-device one, rt_scene_create_multi):
+	 * a pixel's passes are folded strictly in pass order, `mean += (pass-mean)/i`,
 	 * the reference's accumulation (src/main.rs:179-185).  S > 1: the passes of a pixel are split
 	 * into S contiguous chunks [floor(c*spp/S), floor((c+1)*spp/S)) that are folded independently
 	 * (each with its own i = 1..n_c) and combined in chunk order as
@@ -245,6 +246,24 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out);
  * returns RT_ERR_NO_DEVICE (there is no CPU fallback). */
 #define RT_DEVICE_NONE (-1)
 void rt_scene_destroy(rt_scene *scene);
+
+/* ---- one scene on SEVERAL GPUs of the node, behind the same calls.  The reference's caller is one process with one
+ * `Scene::render` (src/scene.rs:35-42) whose sampler partitions the frame into independent chunks
+ * (samplers/random_sampler.rs:45-52); this is that partition across devices: Bvh::new runs once on the host, the scene is
+ * replicated into the HBM of every listed device, tile t of the frame (8 x 8 pixels unless opts say otherwise) belongs to
+ * device t % n_devices.  rt_render / rt_render_device / rt_render_rgb8 / rt_sample_image on the returned handle render every
+ * device's tiles concurrently (one stream per device, no host thread per device, nothing synchronises with the host inside
+ * rt_render_device), gather the shards into the HBM of devices[0] -- grouped ncclSend / ncclRecv (RCCL is loaded on demand
+ * when the devices are distinct; hipMemcpyPeerAsync if it is not usable; a plain copy between members on the same device) --
+ * and write them into the frame there; `rays_shot` is the sum over the devices.  The frame, `d_out_rgb`, `d_rays_shot` and
+ * `hip_stream` belong to devices[0].  opts->shard_count must be 1 and the layout RT_LAYOUT_FRAME: the scene shards by itself.
+ * opts->sample_split: 1 = every pixel folded strictly in pass order, so the frame equals the single-device frame bit for bit
+ * (a device then cannot use more lanes than it owns pixels); 0 = automatic (the power of two that keeps >= 32 work items
+ * per resident lane: 1, 16, 32, 64 for 1, 2, 4, 8 GPUs at 1080p); S > 1 as documented at rt_render_opts.  A list of ONE device is
+ * rt_scene_create.  The same device may be listed more than once (two members then share that GPU).  rt_check_hit[_index]
+ * and the introspection calls use devices[0]. ---- */
+int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, rt_scene **out);
+int rt_scene_device_count(const rt_scene *scene, uint32_t *n_devices); /* 0 for a host-only scene */
 
 /* introspection of what Bvh::new produced (for parity tests against the oracle) */
 int rt_scene_counts(const rt_scene *scene, uint64_t *n_nodes, uint64_t *n_primitives, uint64_t *n_lights);

@@ -185,6 +185,19 @@ class Bvh { // acceleration/mod.rs:44-93, resident in the HBM of `device`
 		const rt_scene_desc d = scene.desc(split);
 		check(rt_scene_create(&d, device, &h_));
 	}
+	// one Bvh replicated over several GPUs of the node: every render through it shards the frame's tiles over `devices`
+	// and gathers into devices[0] (rt_scene_create_multi; the partition of samplers/random_sampler.rs:45-52 across devices)
+	Bvh(const SceneBuilder &scene, const std::vector<int> &devices, SplitType split = SplitType::Sah)
+	{
+		const rt_scene_desc d = scene.desc(split);
+		check(rt_scene_create_multi(&d, devices.data(), (uint32_t)devices.size(), &h_));
+	}
+	uint32_t device_count() const
+	{
+		uint32_t n = 0;
+		check(rt_scene_device_count(h_, &n));
+		return n;
+	}
 	~Bvh() { rt_scene_destroy(h_); }
 	Bvh(const Bvh &) = delete;
 	Bvh &operator=(const Bvh &) = delete;
@@ -217,6 +230,7 @@ class Bvh { // acceleration/mod.rs:44-93, resident in the HBM of `device`
 struct HipSampler {
 	uint64_t batch = 0; // 0 = all passes in one launch
 	uint64_t seed = 1;
+	uint32_t sample_split = 1; // rt_render_opts.sample_split; 0 = automatic on a multi-device Bvh (more lanes than pixels per GPU)
 	uint32_t max_depth = 50, rr_threshold = 3; // integrators/mod.rs:7-8
 
 	// update(data, previous, i) -> bool, the reference's presentation_update: called once per batch with the
@@ -233,6 +247,7 @@ struct HipSampler {
 		opts.render_method = (int32_t)o.render_method;
 		opts.max_depth = max_depth;
 		opts.rr_threshold = rr_threshold;
+		opts.sample_split = sample_split;
 		struct Closure {
 			T *data;
 			F *update;

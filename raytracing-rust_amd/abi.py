@@ -228,6 +228,8 @@ EXPORTED_SYMBOLS = [
     "rt_render_opts_default",
     "rt_camera_new",
     "rt_scene_create",
+    "rt_scene_create_multi",
+    "rt_scene_device_count",
     "rt_scene_destroy",
     "rt_scene_counts",
     "rt_scene_get_nodes",

@@ -16,6 +16,7 @@
 
 #include "../../include/rt_hip.h"
 #include "../../include/rt_detmath.h"
+#include <dlfcn.h>
 #include "rt_build.h"
 #include "rt_types.h"
 
@@ -39,6 +40,8 @@ hipError_t launch_check_hit(bool prune, hipStream_t stream, const DevScene &S, c
 hipError_t launch_trace_queue(int waves, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream, const DevScene &S, const void *rays, uint32_t n, void *out,
                               uint32_t *counter, unsigned long long *steps, uint32_t cap, uint32_t ovf_depth, uint32_t *ovf);
 #endif
+hipError_t launch_scatter_shard(hipStream_t stream, const DevRenderParams &P, const float *shard, float *frame);
+hipError_t launch_sum_u64(hipStream_t stream, const unsigned long long *parts, uint32_t n, unsigned long long *out);
 hipError_t launch_selftest_lean(hipStream_t stream, uint32_t blocks, uint64_t n_per_thread, uint64_t seed, unsigned long long *mismatches);
 hipError_t launch_check_hit_index(bool prune, hipStream_t stream, const DevScene &S, const void *rays, const void *object_index,
                                   uint64_t n, void *out);
@@ -106,10 +109,26 @@ struct rt_scene {
 	rt_launch_info last_launch{};
 	uint32_t stack_cap_override = 0; // RT_TUNE_STACK_CAP
 	int exchange_mode = 0;           // RT_TUNE_EXCHANGE
+	uint32_t stack_depth_narrow = 2; // HostScene::stack_depth_narrow (members of a multi-device scene have no host scene of their own)
 	uint32_t *d_stack_ovf = nullptr; // traversal-stack overflow area (deep trees under the fine schedule), grown on demand
 	size_t stack_ovf_words = 0;
 	uint8_t *d_rgb8 = nullptr; // rt_render_rgb8: the quantised frame
 	size_t d_rgb8_bytes = 0;
+	// ---- multi-device scenes (rt_scene_create_multi).  The handle a caller holds is the HEAD: an ordinary scene on
+	// devices[0] that additionally owns one member scene per further device (uploaded from the head's host build) and
+	// gathers their tile shards into its own frames.  Members render like any single-device scene. ----
+	std::vector<rt_scene *> peers;         // head only: the members on devices[1..n-1]
+	bool member_call = false;              // set while the head renders its own shard through the single-device path
+	float *d_shard = nullptr;              // every member incl. the head: its packed shard (RT_LAYOUT_SHARD)
+	size_t shard_floats = 0;
+	unsigned long long *d_member_rays = nullptr; // the member's own ray counter (the head's d_rays holds the job's total)
+	hipEvent_t ev_shard = nullptr;         // member: its shard is rendered
+	hipEvent_t ev_begin = nullptr;         // head: the caller's stream has reached this render
+	float *d_gather = nullptr;             // head: the peers' shards, once gathered
+	size_t gather_floats = 0;
+	unsigned long long *d_gather_rays = nullptr; // head: [n] the members' ray counters
+	void *nccl_comms = nullptr;            // head: ncclComm_t[n] when the devices are distinct and RCCL is usable
+	int gather_mode = 0;                   // 0 undecided, 1 RCCL send/recv, 2 peer / same-device copies
 };
 
 template <class T> static int upload(rt_scene *s, const T *src, size_t count, const T **dst)
@@ -121,6 +140,208 @@ template <class T> static int upload(rt_scene *s, const T *src, size_t count, co
 	if (count)
 		HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
 	*dst = static_cast<const T *>(p);
+	return RT_OK;
+}
+
+// ---- RCCL, loaded on demand.  The gather of a multi-device render is the one collective of the path:
+// grouped ncclSend / ncclRecv of the members' shards into the head's device over xGMI.  The library is not a link-time
+// dependency (a process that already carries PyTorch's copy must not get a second one bound at load time); it is opened
+// when a scene over DISTINCT devices first renders.  If it is missing or refuses the device list, the same bytes move with
+// hipMemcpyPeerAsync. ----
+struct RcclApi {
+	void *lib = nullptr;
+	int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+	int (*CommDestroy)(void *comm) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Send)(const void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
+	int (*Recv)(void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
+	bool ok = false;
+};
+static RcclApi &rccl()
+{
+	static RcclApi api = [] {
+		RcclApi a;
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (a.lib)
+				break;
+		}
+		if (!a.lib)
+			return a;
+		a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
+		a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+		a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+		a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+		a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
+		a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
+		a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+		return a;
+	}();
+	return api;
+}
+constexpr int kNcclFloat32 = 7; // ncclFloat32 of rccl.h
+
+extern "C" void rt_scene_destroy(rt_scene *s);
+// what a multi-device head owns beyond an ordinary scene
+static void multi_release(rt_scene *s)
+{
+	if (s->nccl_comms) {
+		void **comms = static_cast<void **>(s->nccl_comms);
+		for (size_t i = 0; i < s->peers.size() + 1; ++i)
+			if (comms[i])
+				(void)rccl().CommDestroy(comms[i]);
+		delete[] comms;
+		s->nccl_comms = nullptr;
+	}
+	for (rt_scene *m : s->peers)
+		rt_scene_destroy(m);
+	s->peers.clear();
+	if (s->device != RT_DEVICE_NONE) {
+		(void)hipSetDevice(s->device);
+		if (s->d_shard) (void)hipFree(s->d_shard);
+		if (s->d_gather) (void)hipFree(s->d_gather);
+		if (s->d_gather_rays) (void)hipFree(s->d_gather_rays);
+		if (s->d_member_rays) (void)hipFree(s->d_member_rays);
+		if (s->ev_shard) (void)hipEventDestroy(s->ev_shard);
+		if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+	}
+	s->d_shard = s->d_gather = nullptr;
+	s->d_gather_rays = s->d_member_rays = nullptr;
+	s->ev_shard = s->ev_begin = nullptr;
+}
+
+// Lays a built scene out in the HBM of s->device (every array of rt_types.h) and creates the scene's stream, events and
+// counters.  `h` is only read: the members of a multi-device scene (rt_scene_create_multi) are uploaded from one host build.
+static int upload_scene(rt_scene *s, const HostScene &h)
+{
+	int rc = RT_OK;
+	auto bail = [&](int code) { return code; }; // (the caller destroys the scene)
+	const int device = s->device;
+	if (hipSetDevice(device) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipSetDevice failed"));
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
+	// the texture records and the tiny-scene blob carry device pointers: per-device copies
+	std::vector<DevTexture> textures = h.textures;
+	std::vector<uint32_t> blob;
+	uint32_t blob_off[8] = {};
+	s->n_cus = prop.multiProcessorCount;
+	s->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+
+	DevScene &D = s->dev;
+	std::memset(&D, 0, sizeof D);
+	// per-texture payloads first, so the texture records can point at them
+	for (size_t i = 0; i < h.textures.size(); ++i) {
+		if (!h.tex_images[i].empty()) {
+			if ((rc = upload(s, h.tex_images[i].data(), h.tex_images[i].size(), &textures[i].image)) != RT_OK)
+				return bail(rc);
+		}
+		if (!h.tex_perlin_vecs[i].empty()) {
+			if ((rc = upload(s, h.tex_perlin_vecs[i].data(), h.tex_perlin_vecs[i].size(), &textures[i].perlin_vecs)) != RT_OK)
+				return bail(rc);
+			if ((rc = upload(s, h.tex_perlin_perm[i].data(), h.tex_perlin_perm[i].size(), &textures[i].perlin_perm)) != RT_OK)
+				return bail(rc);
+		}
+	}
+	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
+	if (!h.dev_nodes4.empty()) { // hipMalloc aligns far beyond the 128 bytes a DevNode4 line needs
+		if ((rc = upload(s, h.dev_nodes4.data(), h.dev_nodes4.size(), &D.nodes4)) != RT_OK) return bail(rc);
+		if ((rc = upload(s, h.leaf_box.data(), h.leaf_box.size(), &D.leaf_box)) != RT_OK) return bail(rc);
+	}
+	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.prim_rank.data(), h.prim_rank.size(), &D.prim_rank)) != RT_OK) return bail(rc);
+	{
+		const uint32_t *d_big = nullptr;
+		if ((rc = upload(s, h.big_leaves.data(), h.big_leaves.size(), &d_big)) != RT_OK) return bail(rc);
+		D.big_leaves = reinterpret_cast<const uint2 *>(d_big);
+	}
+	if ((rc = upload(s, h.materials.data(), h.materials.size(), &D.materials)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, textures.data(), textures.size(), &D.textures)) != RT_OK) return bail(rc);
+	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
+	const float *d_sky = nullptr;
+	if ((rc = upload(s, h.sky_cdf.data(), h.sky_cdf.size(), &d_sky)) != RT_OK) return bail(rc);
+	const uint8_t *d_guide = nullptr;
+	if ((rc = upload(s, h.sky_guide.data(), h.sky_guide.size(), &d_guide)) != RT_OK) return bail(rc);
+	{
+		// tiny scenes: one packed copy of every array, staged into LDS by the render kernel.  Built here
+		// (not in rt_build.cpp) because the texture records must already hold their device pointers.
+		auto pad16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+		const size_t sizes[8] = {h.dev_nodes.size() * sizeof(DevNode),      h.dev_prims.size() * sizeof(DevPrim),
+		                         h.dev_shade.size() * sizeof(DevShade),     h.prim_rank.size() * 4,
+		                         h.materials.size() * sizeof(DevMaterial),  textures.size() * sizeof(DevTexture),
+		                         h.dev_lights.size() * 4,                   h.big_leaves.size() * 4};
+		const void *srcs[8] = {h.dev_nodes.data(), h.dev_prims.data(), h.dev_shade.data(), h.prim_rank.data(),
+		                       h.materials.data(), textures.data(),  h.dev_lights.data(), h.big_leaves.data()};
+		size_t total = 0;
+		for (int i = 0; i < 8; ++i) {
+			blob_off[i] = (uint32_t)total;
+			total += pad16(sizes[i]);
+		}
+		if (total <= 12 * 1024) {
+			blob.assign(total / 4, 0u);
+			for (int i = 0; i < 8; ++i)
+				if (sizes[i])
+					std::memcpy(reinterpret_cast<char *>(blob.data()) + blob_off[i], srcs[i], sizes[i]);
+			if ((rc = upload(s, blob.data(), blob.size(), &D.blob)) != RT_OK) return bail(rc);
+			D.blob_bytes = (uint32_t)total;
+			D.off_nodes = blob_off[0]; D.off_prims = blob_off[1]; D.off_shade = blob_off[2]; D.off_rank = blob_off[3];
+			D.off_materials = blob_off[4]; D.off_textures = blob_off[5]; D.off_lights = blob_off[6]; D.off_big_leaves = blob_off[7];
+		}
+	}
+
+	D.n_nodes = (uint32_t)h.dev_nodes.size();
+	D.n_prims = (uint32_t)h.dev_prims.size();
+	D.n_lights = (uint32_t)h.dev_lights.size();
+	D.n_materials = (uint32_t)h.materials.size();
+	D.n_textures = (uint32_t)h.textures.size();
+	D.root_ref = h.root_ref;
+	D.root4_ref = h.root4_ref;
+	D.n_nodes4 = (uint32_t)h.dev_nodes4.size();
+	std::memcpy(D.root_min, h.root_min, sizeof D.root_min);
+	std::memcpy(D.root_max, h.root_max, sizeof D.root_max);
+	D.stack_depth = h.stack_depth;
+	s->stack_depth_narrow = h.stack_depth_narrow;
+	D.has_triangles = h.has_triangles ? 1u : 0u;
+	D.sky.texture = h.sky.texture;
+	D.sky.material = h.sky.material;
+	D.sky.res_x = h.sky.sampler_res_x;
+	D.sky.res_y = h.sky.sampler_res_y;
+	D.sky.row_cdf = d_sky;
+	D.sky.marginal_cdf = d_sky + (size_t)h.sky.sampler_res_y * (h.sky.sampler_res_x + 1u);
+	D.sky.guide = h.sky_guide_k ? d_guide : nullptr;
+	D.sky.guide_k = h.sky_guide_k;
+
+	void *p = nullptr;
+	if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc work counter"));
+	s->allocations.push_back(p);
+	s->d_work_counter = static_cast<uint32_t *>(p);
+	if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc rays"));
+	s->allocations.push_back(p);
+	s->d_rays = static_cast<unsigned long long *>(p);
+	if (hipStreamCreate(&s->stream) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
+	if (hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
+		return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
+	{ // which kernel variant covers this scene (rt_types.h Feat)
+		bool cmat = false, ctex = false;
+		for (const DevMaterial &m : h.materials)
+			cmat = cmat || (m.type != RT_MAT_EMIT && m.type != RT_MAT_LAMBERTIAN);
+		for (const DevTexture &t : textures)
+			ctex = ctex || (t.type != RT_TEX_SOLID && t.type != RT_TEX_LERP);
+		if (cmat || ctex)
+			s->feature_set = 2;
+		else if (h.has_triangles || !h.lights.empty())
+			s->feature_set = 1;
+		else
+			s->feature_set = 0;
+		s->min_feature_set = s->feature_set;
+	}
+	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
+		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
+		if (std::strcmp(e, "pruned") == 0) s->traversal_mode = 1;
+	}
 	return RT_OK;
 }
 
@@ -170,6 +391,7 @@ void rt_scene_destroy(rt_scene *s)
 		delete s;
 		return;
 	}
+	multi_release(s);
 	(void)hipSetDevice(s->device);
 	for (void *p : s->allocations)
 		(void)hipFree(p);
@@ -228,132 +450,65 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out)
 		delete s;
 		return fail(rc, err);
 	}
-	HostScene &h = s->host;
-
-	auto bail = [&](int code) {
+	rc = upload_scene(s, s->host);
+	if (rc != RT_OK) {
 		rt_scene_destroy(s);
-		return code;
-	};
-	if (hipSetDevice(device) != hipSuccess)
-		return bail(fail(RT_ERR_HIP, "hipSetDevice failed"));
-	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
-		return bail(fail(RT_ERR_HIP, "hipGetDeviceProperties failed"));
-	s->n_cus = prop.multiProcessorCount;
-	s->max_lds = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
-
-	DevScene &D = s->dev;
-	std::memset(&D, 0, sizeof D);
-	// per-texture payloads first, so the texture records can point at them
-	for (size_t i = 0; i < h.textures.size(); ++i) {
-		if (!h.tex_images[i].empty()) {
-			if ((rc = upload(s, h.tex_images[i].data(), h.tex_images[i].size(), &h.textures[i].image)) != RT_OK)
-				return bail(rc);
-		}
-		if (!h.tex_perlin_vecs[i].empty()) {
-			if ((rc = upload(s, h.tex_perlin_vecs[i].data(), h.tex_perlin_vecs[i].size(), &h.textures[i].perlin_vecs)) != RT_OK)
-				return bail(rc);
-			if ((rc = upload(s, h.tex_perlin_perm[i].data(), h.tex_perlin_perm[i].size(), &h.textures[i].perlin_perm)) != RT_OK)
-				return bail(rc);
-		}
-	}
-	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
-	if (!h.dev_nodes4.empty()) { // hipMalloc aligns far beyond the 128 bytes a DevNode4 line needs
-		if ((rc = upload(s, h.dev_nodes4.data(), h.dev_nodes4.size(), &D.nodes4)) != RT_OK) return bail(rc);
-		if ((rc = upload(s, h.leaf_box.data(), h.leaf_box.size(), &D.leaf_box)) != RT_OK) return bail(rc);
-	}
-	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
-	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);
-	if ((rc = upload(s, h.prim_rank.data(), h.prim_rank.size(), &D.prim_rank)) != RT_OK) return bail(rc);
-	{
-		const uint32_t *d_big = nullptr;
-		if ((rc = upload(s, h.big_leaves.data(), h.big_leaves.size(), &d_big)) != RT_OK) return bail(rc);
-		D.big_leaves = reinterpret_cast<const uint2 *>(d_big);
-	}
-	if ((rc = upload(s, h.materials.data(), h.materials.size(), &D.materials)) != RT_OK) return bail(rc);
-	if ((rc = upload(s, h.textures.data(), h.textures.size(), &D.textures)) != RT_OK) return bail(rc);
-	if ((rc = upload(s, h.dev_lights.data(), h.dev_lights.size(), &D.lights)) != RT_OK) return bail(rc);
-	const float *d_sky = nullptr;
-	if ((rc = upload(s, h.sky_cdf.data(), h.sky_cdf.size(), &d_sky)) != RT_OK) return bail(rc);
-	const uint8_t *d_guide = nullptr;
-	if ((rc = upload(s, h.sky_guide.data(), h.sky_guide.size(), &d_guide)) != RT_OK) return bail(rc);
-	{
-		// tiny scenes: one packed copy of every array, staged into LDS by the render kernel.  Built here
-		// (not in rt_build.cpp) because the texture records must already hold their device pointers.
-		auto pad16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
-		const size_t sizes[8] = {h.dev_nodes.size() * sizeof(DevNode),      h.dev_prims.size() * sizeof(DevPrim),
-		                         h.dev_shade.size() * sizeof(DevShade),     h.prim_rank.size() * 4,
-		                         h.materials.size() * sizeof(DevMaterial),  h.textures.size() * sizeof(DevTexture),
-		                         h.dev_lights.size() * 4,                   h.big_leaves.size() * 4};
-		const void *srcs[8] = {h.dev_nodes.data(), h.dev_prims.data(), h.dev_shade.data(), h.prim_rank.data(),
-		                       h.materials.data(), h.textures.data(),  h.dev_lights.data(), h.big_leaves.data()};
-		size_t total = 0;
-		for (int i = 0; i < 8; ++i) {
-			h.blob_off[i] = (uint32_t)total;
-			total += pad16(sizes[i]);
-		}
-		if (total <= 12 * 1024) {
-			h.blob.assign(total / 4, 0u);
-			for (int i = 0; i < 8; ++i)
-				if (sizes[i])
-					std::memcpy(reinterpret_cast<char *>(h.blob.data()) + h.blob_off[i], srcs[i], sizes[i]);
-			if ((rc = upload(s, h.blob.data(), h.blob.size(), &D.blob)) != RT_OK) return bail(rc);
-			D.blob_bytes = (uint32_t)total;
-			D.off_nodes = h.blob_off[0]; D.off_prims = h.blob_off[1]; D.off_shade = h.blob_off[2]; D.off_rank = h.blob_off[3];
-			D.off_materials = h.blob_off[4]; D.off_textures = h.blob_off[5]; D.off_lights = h.blob_off[6]; D.off_big_leaves = h.blob_off[7];
-		}
-	}
-
-	D.n_nodes = (uint32_t)h.dev_nodes.size();
-	D.n_prims = (uint32_t)h.dev_prims.size();
-	D.n_lights = (uint32_t)h.dev_lights.size();
-	D.n_materials = (uint32_t)h.materials.size();
-	D.n_textures = (uint32_t)h.textures.size();
-	D.root_ref = h.root_ref;
-	D.root4_ref = h.root4_ref;
-	D.n_nodes4 = (uint32_t)h.dev_nodes4.size();
-	std::memcpy(D.root_min, h.root_min, sizeof D.root_min);
-	std::memcpy(D.root_max, h.root_max, sizeof D.root_max);
-	D.stack_depth = h.stack_depth;
-	D.has_triangles = h.has_triangles ? 1u : 0u;
-	D.sky.texture = h.sky.texture;
-	D.sky.material = h.sky.material;
-	D.sky.res_x = h.sky.sampler_res_x;
-	D.sky.res_y = h.sky.sampler_res_y;
-	D.sky.row_cdf = d_sky;
-	D.sky.marginal_cdf = d_sky + (size_t)h.sky.sampler_res_y * (h.sky.sampler_res_x + 1u);
-	D.sky.guide = h.sky_guide_k ? d_guide : nullptr;
-	D.sky.guide_k = h.sky_guide_k;
-
-	void *p = nullptr;
-	if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc work counter"));
-	s->allocations.push_back(p);
-	s->d_work_counter = static_cast<uint32_t *>(p);
-	if (hipMalloc(&p, sizeof(unsigned long long)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc rays"));
-	s->allocations.push_back(p);
-	s->d_rays = static_cast<unsigned long long *>(p);
-	if (hipStreamCreate(&s->stream) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
-	if (hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
-		return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
-	{ // which kernel variant covers this scene (rt_types.h Feat)
-		bool cmat = false, ctex = false;
-		for (const DevMaterial &m : h.materials)
-			cmat = cmat || (m.type != RT_MAT_EMIT && m.type != RT_MAT_LAMBERTIAN);
-		for (const DevTexture &t : h.textures)
-			ctex = ctex || (t.type != RT_TEX_SOLID && t.type != RT_TEX_LERP);
-		if (cmat || ctex)
-			s->feature_set = 2;
-		else if (h.has_triangles || !h.lights.empty())
-			s->feature_set = 1;
-		else
-			s->feature_set = 0;
-		s->min_feature_set = s->feature_set;
-	}
-	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
-		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
-		if (std::strcmp(e, "pruned") == 0) s->traversal_mode = 1;
+		return rc;
 	}
 	*out = s;
+	return RT_OK;
+}
+
+int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, rt_scene **out)
+{
+	if (!desc || !out || !devices || n_devices == 0)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument or empty device list");
+	*out = nullptr;
+	if (n_devices > 64)
+		return fail(RT_ERR_INVALID_ARGUMENT, "more than 64 devices");
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+		return fail(RT_ERR_NO_DEVICE, "no HIP device: the rt_hip back end has no CPU fallback");
+	for (uint32_t i = 0; i < n_devices; ++i)
+		if (devices[i] < 0 || devices[i] >= n_dev)
+			return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+	rt_scene *head = nullptr;
+	int rc = rt_scene_create(desc, devices[0], &head); // Bvh::new once, on the host
+	if (rc != RT_OK)
+		return rc;
+	for (uint32_t i = 1; i < n_devices; ++i) { // the same arrays in the HBM of every further device
+		rt_scene *m = new rt_scene();
+		m->device = devices[i];
+		head->peers.push_back(m);
+		rc = upload_scene(m, head->host);
+		if (rc != RT_OK) {
+			rt_scene_destroy(head);
+			return rc;
+		}
+	}
+	std::vector<rt_scene *> members{head};
+	members.insert(members.end(), head->peers.begin(), head->peers.end());
+	for (rt_scene *m : members) {
+		if (hipSetDevice(m->device) != hipSuccess || hipEventCreateWithFlags(&m->ev_shard, hipEventDisableTiming) != hipSuccess ||
+		    hipMalloc(reinterpret_cast<void **>(&m->d_member_rays), sizeof(unsigned long long)) != hipSuccess) {
+			rt_scene_destroy(head);
+			return fail(RT_ERR_HIP, "multi-device scene: event / counter allocation failed");
+		}
+	}
+	if (hipSetDevice(head->device) != hipSuccess || hipEventCreateWithFlags(&head->ev_begin, hipEventDisableTiming) != hipSuccess ||
+	    hipMalloc(reinterpret_cast<void **>(&head->d_gather_rays), n_devices * sizeof(unsigned long long)) != hipSuccess) {
+		rt_scene_destroy(head);
+		return fail(RT_ERR_HIP, "multi-device scene: event / counter allocation failed");
+	}
+	*out = head;
+	return RT_OK;
+}
+
+int rt_scene_device_count(const rt_scene *s, uint32_t *n_devices)
+{
+	if (!s || !n_devices)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	*n_devices = s->device == RT_DEVICE_NONE ? 0u : (uint32_t)(1 + s->peers.size());
 	return RT_OK;
 }
 
@@ -362,13 +517,25 @@ int rt_scene_set_traversal(rt_scene *s, int mode)
 	if (!s || mode < -1 || mode > 1)
 		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
 	s->traversal_mode = mode;
+	for (rt_scene *m : s->peers)
+		m->traversal_mode = mode;
 	return RT_OK;
 }
 
+static int set_tuning_one(rt_scene *s, int key, int value);
 int rt_scene_set_tuning(rt_scene *s, int key, int value)
 {
 	if (!s)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null scene");
+	const int rc = set_tuning_one(s, key, value);
+	for (rt_scene *m : s->peers) // the members of a multi-device scene run the same kernels
+		if (rc == RT_OK) {
+			(void)set_tuning_one(m, key, value);
+		}
+	return rc;
+}
+static int set_tuning_one(rt_scene *s, int key, int value)
+{
 	switch (key) {
 	case RT_TUNE_TRAVERSAL:
 		return rt_scene_set_traversal(s, value);
@@ -569,11 +736,188 @@ int rt_shard_pixel_order(const rt_render_opts *o, uint64_t *out, uint64_t capaci
 	return RT_OK;
 }
 
+// ---- a render on a multi-device scene (rt_scene_create_multi): `d_out_rgb` / `d_rays_shot` live on the HEAD's device and
+// `hip_stream` is a stream of that device, exactly as for a single-device scene.  Tile t of the frame belongs to member
+// t % n (the partition of DESIGN.md section 7); every member renders its tiles packed (RT_LAYOUT_SHARD) on its own
+// stream, the head on the caller's; the peers' shards are gathered into the head's HBM -- grouped ncclSend / ncclRecv
+// when the devices are distinct and RCCL is usable, hipMemcpyPeerAsync otherwise (same-device members: a plain copy) --
+// and one small kernel per shard writes them into the frame.  Nothing synchronises with the host. ----
+static int multi_sample_split(const rt_scene *head, const rt_render_opts *o, uint32_t n)
+{
+	// A lane folds a whole pixel, so a member cannot use more lanes than it owns pixels: split the passes of a pixel into
+	// the power of two of chunks that keeps >= 32 work items per resident lane (measured on one GPU's share of an 8-way
+	// sharded 1080p frame: 42.9 ms at S = 1, 17.5 ms at S = 64, ideal 15.4 ms)
+	const uint64_t lanes = (uint64_t)head->n_cus * 1024u;
+	uint32_t split = 1;
+	while (n > 1 && (o->width * o->height / n) * split < 32 * lanes && split < o->samples_per_pixel / 16)
+		split *= 2;
+	return (int)split;
+}
+
+static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt_render_opts *o, float *d_out_rgb, uint64_t *d_rays_shot,
+                               hipStream_t stream)
+{
+	if (o->shard_count != 1 || o->shard_index != 0 || o->output_layout != RT_LAYOUT_FRAME)
+		return fail(RT_ERR_UNSUPPORTED, "a multi-device scene shards the frame over its own devices: shard_count must be 1 and the layout RT_LAYOUT_FRAME");
+	std::vector<rt_scene *> members{head};
+	members.insert(members.end(), head->peers.begin(), head->peers.end());
+	const uint32_t n = (uint32_t)members.size();
+	rt_render_opts om = *o;
+	om.shard_count = n;
+	om.output_layout = RT_LAYOUT_SHARD;
+	if (om.sample_split == 0) // 0 = automatic on a multi-device scene; 1 = the reference's strictly sequential fold
+		om.sample_split = (uint32_t)multi_sample_split(head, o, n);
+	if (om.sample_split > om.samples_per_pixel)
+		om.sample_split = (uint32_t)om.samples_per_pixel;
+
+	std::vector<uint64_t> n_floats(n, 0), offset(n, 0);
+	uint64_t gather_total = 0;
+	for (uint32_t m = 0; m < n; ++m) {
+		om.shard_index = m;
+		int rc = rt_render_output_floats(&om, &n_floats[m]);
+		if (rc != RT_OK)
+			return rc;
+		if (m > 0) {
+			offset[m] = gather_total;
+			gather_total += n_floats[m];
+		}
+	}
+	HIP_TRY(hipSetDevice(head->device));
+	if (gather_total > head->gather_floats) { // grown on first use / larger frames only
+		if (head->d_gather)
+			(void)hipFree(head->d_gather);
+		head->d_gather = nullptr;
+		head->gather_floats = 0;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&head->d_gather), gather_total * sizeof(float)));
+		head->gather_floats = gather_total;
+	}
+	HIP_TRY(hipEventRecord(head->ev_begin, stream)); // the peers start once the caller's stream has reached this call
+
+	// ---- every member renders its shard ----
+	for (uint32_t m = 0; m < n; ++m) {
+		rt_scene *mem = members[m];
+		if (n_floats[m] == 0)
+			continue;
+		HIP_TRY(hipSetDevice(mem->device));
+		if (n_floats[m] > mem->shard_floats) {
+			if (mem->d_shard)
+				(void)hipFree(mem->d_shard);
+			mem->d_shard = nullptr;
+			mem->shard_floats = 0;
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mem->d_shard), n_floats[m] * sizeof(float)));
+			mem->shard_floats = n_floats[m];
+		}
+		hipStream_t ms = m == 0 ? stream : mem->stream;
+		if (m > 0)
+			HIP_TRY(hipStreamWaitEvent(ms, head->ev_begin, 0));
+		om.shard_index = m;
+		mem->member_call = true;
+		const int rc = rt_render_device(mem, camera, &om, mem->d_shard, reinterpret_cast<uint64_t *>(mem->d_member_rays), ms);
+		mem->member_call = false;
+		if (rc != RT_OK)
+			return rc;
+		if (m > 0)
+			HIP_TRY(hipEventRecord(mem->ev_shard, ms));
+	}
+
+	// ---- gather the peers' shards (and ray counters) into the head's HBM ----
+	HIP_TRY(hipSetDevice(head->device));
+	if (head->gather_mode == 0) { // decided once: RCCL needs distinct devices
+		bool distinct = true;
+		for (uint32_t a = 0; a < n; ++a)
+			for (uint32_t b = a + 1; b < n; ++b)
+				distinct = distinct && members[a]->device != members[b]->device;
+		head->gather_mode = 2;
+		if (n > 1 && distinct && rccl().ok && std::getenv("RT_HIP_NO_RCCL") == nullptr) {
+			void **comms = new void *[n]();
+			std::vector<int> devs(n);
+			for (uint32_t m = 0; m < n; ++m)
+				devs[m] = members[m]->device;
+			if (rccl().CommInitAll(comms, (int)n, devs.data()) == 0) {
+				head->nccl_comms = comms;
+				head->gather_mode = 1;
+			} else {
+				delete[] comms;
+			}
+			HIP_TRY(hipSetDevice(head->device));
+		}
+	}
+	if (head->gather_mode == 1) {
+		void **comms = static_cast<void **>(head->nccl_comms);
+		if (rccl().GroupStart() != 0)
+			return fail(RT_ERR_HIP, "ncclGroupStart failed");
+		int bad = 0;
+		for (uint32_t m = 1; m < n; ++m) {
+			if (n_floats[m] == 0)
+				continue;
+			bad |= rccl().Send(members[m]->d_shard, n_floats[m], kNcclFloat32, 0, comms[m], members[m]->stream);
+			bad |= rccl().Recv(head->d_gather + offset[m], n_floats[m], kNcclFloat32, (int)m, comms[0], stream);
+		}
+		if (rccl().GroupEnd() != 0 || bad != 0)
+			return fail(RT_ERR_HIP, "RCCL shard gather failed");
+		HIP_TRY(hipSetDevice(head->device));
+	} else {
+		for (uint32_t m = 1; m < n; ++m) {
+			if (n_floats[m] == 0)
+				continue;
+			HIP_TRY(hipStreamWaitEvent(stream, members[m]->ev_shard, 0));
+			if (members[m]->device == head->device)
+				HIP_TRY(hipMemcpyAsync(head->d_gather + offset[m], members[m]->d_shard, n_floats[m] * sizeof(float), hipMemcpyDeviceToDevice, stream));
+			else
+				HIP_TRY(hipMemcpyPeerAsync(head->d_gather + offset[m], head->device, members[m]->d_shard, members[m]->device, n_floats[m] * sizeof(float), stream));
+		}
+	}
+	// ---- scatter the shards into the frame (every pixel belongs to exactly one shard: nothing to clear) ----
+	for (uint32_t m = 0; m < n; ++m) {
+		if (n_floats[m] == 0)
+			continue;
+		om.shard_index = m;
+		ShardGeometry g;
+		int rc = shard_geometry(&om, g);
+		if (rc != RT_OK)
+			return rc;
+		DevRenderParams P;
+		std::memset(&P, 0, sizeof P);
+		P.width = (uint32_t)o->width;
+		P.height = (uint32_t)o->height;
+		P.shard_index = m;
+		P.shard_count = n;
+		P.tile_w = g.tile_w;
+		P.tile_h = g.tile_h;
+		P.tiles_x = g.tiles_x;
+		P.tiles_y = g.tiles_y;
+		P.n_work = (uint32_t)g.n_work;
+		HIP_TRY(launch_scatter_shard(stream, P, m == 0 ? head->d_shard : head->d_gather + offset[m], d_out_rgb));
+	}
+	if (d_rays_shot) { // SamplerProgress.rays_shot of the whole job
+		for (uint32_t m = 0; m < n; ++m) {
+			if (n_floats[m] == 0) {
+				HIP_TRY(hipMemsetAsync(head->d_gather_rays + m, 0, sizeof(unsigned long long), stream));
+			} else if (members[m]->device == head->device) {
+				if (m > 0 && head->gather_mode == 1)
+					HIP_TRY(hipStreamWaitEvent(stream, members[m]->ev_shard, 0));
+				HIP_TRY(hipMemcpyAsync(head->d_gather_rays + m, members[m]->d_member_rays, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+			} else {
+				if (head->gather_mode == 1)
+					HIP_TRY(hipStreamWaitEvent(stream, members[m]->ev_shard, 0));
+				HIP_TRY(hipMemcpyPeerAsync(head->d_gather_rays + m, head->device, members[m]->d_member_rays, members[m]->device, sizeof(unsigned long long), stream));
+			}
+		}
+		HIP_TRY(launch_sum_u64(stream, head->d_gather_rays, n, reinterpret_cast<unsigned long long *>(d_rays_shot)));
+	}
+	return RT_OK;
+}
+
 int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts *o, float *d_out_rgb, uint64_t *d_rays_shot,
                      void *hip_stream)
 {
 	if (!s || !camera || !o || !d_out_rgb)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (!s->peers.empty() && !s->member_call) {
+		if (s->device == RT_DEVICE_NONE)
+			return fail(RT_ERR_NO_DEVICE, "host-only scene");
+		return render_device_multi(s, camera, o, d_out_rgb, d_rays_shot, static_cast<hipStream_t>(hip_stream));
+	}
 	ShardGeometry g;
 	int rc = shard_geometry(o, g);
 	if (rc != RT_OK)
@@ -668,7 +1012,19 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	// the wide tree) is far above what walks reach, and LDS sized for it would cost resident waves; under the fine
 	// schedule the LDS part is capped at the share a workgroup gets at the occupancy its register budget allows, the
 	// rest of the worst case lives in a global overflow area that is touched only if a walk really gets that deep.
-	uint32_t stack_cap = s->dev.stack_depth;
+	// The coarse kernels keep a walk's WHOLE worst-case stack in LDS.  The wide tree's worst case (three pending siblings
+	// per level) is about 1.5 x the two-child tree's, and only pruned walks of regular rays descend it: an exhaustive
+	// launch needs the two-child depth only, and a pruned coarse launch whose wide worst case does not fit the LDS of a CU
+	// (a deep, skewed tree) walks the two-child tree for every ray instead of failing.
+	DevScene dev = s->dev; // what this launch sees
+	const bool walks_wide = prune && dev.nodes4 != nullptr && dev.narrow_only == 0u;
+	uint32_t stack_need = (fine || walks_wide) ? dev.stack_depth : s->stack_depth_narrow;
+	if (!fine && walks_wide &&
+	    render_lds_bytes(dev, false, scene_lds, render_block_threads(s->feature_set, false, false) / 64u, stack_need) > s->max_lds) {
+		dev.narrow_only = 1u;
+		stack_need = s->stack_depth_narrow;
+	}
+	uint32_t stack_cap = stack_need;
 	if (fine) {
 		const uint32_t blocks_wanted = std::max(1u, render_waves_per_simd(s->feature_set, true) * 256u / block_threads);
 		const size_t share = s->max_lds / blocks_wanted;
@@ -676,16 +1032,16 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		stack_cap = std::min(stack_cap, std::max(8u, fit));
 	}
 	if (fine && s->stack_cap_override != 0u) // (coarse kernels keep the whole stack in LDS and walk without capacity checks)
-		stack_cap = std::min(s->dev.stack_depth, s->stack_cap_override);
+		stack_cap = std::min(stack_need, s->stack_cap_override);
 	P.stack_cap = stack_cap;
-	P.stack_ovf_depth = s->dev.stack_depth - stack_cap;
-	size_t lds_bytes = render_lds_bytes(s->dev, false, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
+	P.stack_ovf_depth = stack_need - stack_cap;
+	size_t lds_bytes = render_lds_bytes(dev, false, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
 	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu, xchg_fine));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(s->dev, true, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
+		const size_t lds_with = render_lds_bytes(dev, true, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
 		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with, xchg_fine) == hipSuccess &&
@@ -772,7 +1128,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		}
 	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
-	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, s->dev, cam, P, render_target,
+	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
@@ -961,6 +1317,17 @@ int rt_last_kernel_ms(rt_scene *s, float *ms, uint32_t *n_launches)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipEventSynchronize(s->ev_stop));
 	HIP_TRY(hipEventElapsedTime(ms, s->ev_start, s->ev_stop));
+	for (rt_scene *m : s->peers) { // multi-device scene: the slowest member's kernel
+		if (!m->timed)
+			continue;
+		float mm = 0.0f;
+		HIP_TRY(hipSetDevice(m->device));
+		HIP_TRY(hipEventSynchronize(m->ev_stop));
+		HIP_TRY(hipEventElapsedTime(&mm, m->ev_start, m->ev_stop));
+		*ms = std::max(*ms, mm);
+	}
+	if (!s->peers.empty())
+		HIP_TRY(hipSetDevice(s->device));
 	if (n_launches)
 		*n_launches = s->n_launches;
 	return RT_OK;
@@ -1263,9 +1630,18 @@ static int check_common(rt_scene *s, const rt_ray_desc *rays, const uint64_t *ob
 	if (e == hipSuccess && object_index)
 		e = hipMemcpyAsync(d_idx, object_index, n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream);
 	const bool prune = s->traversal_mode == -1 ? s->dev.n_prims > kPruneAbove : s->traversal_mode == 1;
+	// the batch kernels keep the whole worst-case stack of four waves in LDS: the wide tree's only where it is walked and
+	// fits, the two-child tree's (and the two-child walk for every ray) otherwise -- as rt_render_device does
+	DevScene dev = s->dev;
+	const bool walks_wide = prune && dev.nodes4 != nullptr && dev.narrow_only == 0u;
+	if (!walks_wide || (size_t)4 * dev.stack_depth * 64u * sizeof(uint32_t) > s->max_lds) {
+		if (walks_wide)
+			dev.narrow_only = 1u;
+		dev.stack_depth = s->stack_depth_narrow;
+	}
 	if (e == hipSuccess)
-		e = object_index ? launch_check_hit_index(prune, s->stream, s->dev, d_rays, d_idx, n, d_out)
-		                 : launch_check_hit(prune, s->stream, s->dev, d_rays, n, d_out);
+		e = object_index ? launch_check_hit_index(prune, s->stream, dev, d_rays, d_idx, n, d_out)
+		                 : launch_check_hit(prune, s->stream, dev, d_rays, n, d_out);
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(out, d_out, n * sizeof(rt_hit_record), hipMemcpyDeviceToHost, s->stream);
 	if (e == hipSuccess)

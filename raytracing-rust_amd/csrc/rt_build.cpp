@@ -635,6 +635,7 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		hs.root_ref = leaf_ref(root);
 	}
 	hs.stack_depth = max_depth + 1;
+	hs.stack_depth_narrow = hs.stack_depth;
 
 	// ---- wide tree: the reference tree collapsed to up to four children per node (rt_types.h DevNodeQ4).
 	// A node's children start as its two reference children; the inner child with the largest surface area is

@@ -45,7 +45,8 @@ struct HostScene {
 	uint32_t sky_guide_k = 0;
 	rt_sky_desc sky;
 	float root_min[3], root_max[3];
-	uint32_t stack_depth = 2;
+	uint32_t stack_depth = 2;        // traversal stack entries per lane: enough for the two-child AND the wide walk
+	uint32_t stack_depth_narrow = 2; // ... for the two-child walk alone (all an exhaustive or narrow-only launch needs)
 	bool has_triangles = false;
 };
 

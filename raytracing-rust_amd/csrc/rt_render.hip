@@ -220,6 +220,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	const KArgs K = &args_by_value;
 	auto kargs = [&]() -> KArgs { return K; };
 #endif
+	// (Passing the node / primitive / rank arrays of the two-leaf walk as separate `const __restrict__` kernel arguments turns
+	// its loads back into scalar loads -- through this struct they are vector loads of a uniform address -- but measured nothing
+	// on configs 2 and 3 and cost the fine MIS kernels 10 % (1 M triangles 50.1 -> 55.5 ms, same-box A/B): three more
+	// arguments shifted their register allocation.)
 	const DevScene S_global = K->S;
 	const DevRenderParams P = K->P; // (fields used only through kargs() are never loaded from this copy)
 	uint32_t *const stack_ovf = K->stack_ovf;
@@ -413,8 +417,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		const V3 cam_h = v3(k->cam.horizontal[0], k->cam.horizontal[1], k->cam.horizontal[2]);
 		const V3 cam_v = v3(k->cam.vertical[0], k->cam.vertical[1], k->cam.vertical[2]);
 		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + chunk_begin + sample_local);
-		const float u = (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px) / (float)(k->P.width - 1u);
-		const float v = 1.0f - (rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py) / (float)(k->P.height - 1u);
+		// (jitter + pixel) / (W - 1): the numerator is zero or in [2^-23, 2^31), the denominator in [1, 2^31]: tame (rt_lean.h)
+		const float u = div_tame_fix_(rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px, (float)(k->P.width - 1u));
+		const float v = 1.0f - div_tame_fix_(rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py, (float)(k->P.height - 1u));
 		// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
 		ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
 		(void)rt_rng_f32(&rng);
@@ -1397,6 +1402,40 @@ hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values
 	if (blocks > 8192)
 		blocks = 8192;
 	hipLaunchKernelGGL(quantise_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, rgb, n_values, inv_gamma, out);
+	return hipGetLastError();
+}
+
+// ---- multi-device scenes (rt_scene_create_multi): a member's packed shard (RT_LAYOUT_SHARD: its tiles in work order) is
+// written into the frame on the gathering device.  The index map is the render kernel's own work_to_pixel. ----
+__global__ __launch_bounds__(256) void scatter_shard_kernel(const DevRenderParams P, const float *__restrict__ shard, float *__restrict__ frame)
+{
+	const uint32_t wp = blockIdx.x * blockDim.x + threadIdx.x;
+	if (wp >= P.n_work)
+		return;
+	uint32_t x, y;
+	if (!work_to_pixel(P, wp, x, y))
+		return; // edge-tile padding
+	const size_t o = (size_t)y * P.width + x;
+	frame[3u * o + 0u] = shard[3u * (size_t)wp + 0u];
+	frame[3u * o + 1u] = shard[3u * (size_t)wp + 1u];
+	frame[3u * o + 2u] = shard[3u * (size_t)wp + 2u];
+}
+hipError_t launch_scatter_shard(hipStream_t stream, const DevRenderParams &P, const float *shard, float *frame)
+{
+	hipLaunchKernelGGL(scatter_shard_kernel, dim3((P.n_work + 255u) / 256u), dim3(256), 0, stream, P, shard, frame);
+	return hipGetLastError();
+}
+// SamplerProgress.rays_shot of a multi-device render: the members' counters, summed on the gathering device
+__global__ void sum_u64_kernel(const unsigned long long *__restrict__ parts, uint32_t n, unsigned long long *__restrict__ out)
+{
+	unsigned long long t = 0;
+	for (uint32_t i = 0; i < n; ++i)
+		t += parts[i];
+	*out = t;
+}
+hipError_t launch_sum_u64(hipStream_t stream, const unsigned long long *parts, uint32_t n, unsigned long long *out)
+{
+	hipLaunchKernelGGL(sum_u64_kernel, dim3(1), dim3(1), 0, stream, parts, n, out);
 	return hipGetLastError();
 }
 

@@ -21,6 +21,15 @@ __device__ __forceinline__ float sqrt_unit_(float x)
 	return sqrtf(x);
 #endif
 }
+// n / d for a tame d and an n that is provably zero, infinite, NaN or tame (each use says why)
+__device__ __forceinline__ float div_tame_fix_(float n, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_LEAN)
+	return lean_div_fix(n, d);
+#else
+	return n / d;
+#endif
+}
 
 // ---- utility/mod.rs ----
 __device__ __forceinline__ float next_float(float f) // :51-65
@@ -237,7 +246,7 @@ __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, 
 	if (phi < 0.0f)
 		phi += 2.0f * kPi;
 	const float u = phi / (2.0f * kPi);
-	const float v = theta / kPi;
+	const float v = div_tame_fix_(theta, kPi); // acos returns zero, NaN or at least 2 asin(2^-12.5) = 3.4e-4
 	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
 	uint32_t ui = f32_as_index((float)rx * u);
 	uint32_t vi = f32_as_index((float)ry * v);

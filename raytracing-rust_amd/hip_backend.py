@@ -101,11 +101,26 @@ class HipScene:
     """Bvh::new(primitives, sky, split_type) + upload to the HBM of `device`
     (device=abi.RT_DEVICE_NONE: the host-side tree only; rendering then raises RT_ERR_NO_DEVICE)."""
 
-    def __init__(self, scene_description, device=0):
+    def __init__(self, scene_description, device=0, devices=None):
+        """devices=[d0, d1, ...]: ONE scene replicated over several GPUs (rt_scene_create_multi): every render call shards the
+        frame's tiles over them and gathers into d0's HBM."""
         self._desc = scene_description.desc()
         self._h = C.c_void_p()
-        self.device = device
-        _check(lib().rt_scene_create(C.byref(self._desc), C.c_int(device), C.byref(self._h)))
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            self.device = devices[0]
+            self.devices = devices
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().rt_scene_create_multi(C.byref(self._desc), arr, C.c_uint32(len(devices)), C.byref(self._h)))
+        else:
+            self.device = device
+            self.devices = [device]
+            _check(lib().rt_scene_create(C.byref(self._desc), C.c_int(device), C.byref(self._h)))
+
+    def device_count(self):
+        n = C.c_uint32()
+        _check(lib().rt_scene_device_count(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if self._h:

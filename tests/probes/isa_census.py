@@ -65,7 +65,41 @@ def census(ops):
     out['useful_valu_share'] = round(1.0 - moves / valu, 4) if valu else None
     return out
 
+def write_committed_census():
+    """profiles/valu_census.json: the census of every render kernel of the CURRENT sources (compiles rt_render.hip to
+    assembly with the Makefile's flags, ~80 s), keyed by the kernel name rt_last_launch_info / rocprofv3 print and tied to
+    the hash of the kernel sources.  bench.py reads roofline.useful_valu_share from it."""
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, root)
+    import bench
+    csrc = os.path.join(root, "raytracing-rust_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rt_render.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                        "-fno-gpu-rdc", "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "--cuda-device-only", "-S",
+                        os.path.join(csrc, "rt_render.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+        ks, meta = parse(out)
+    names = [k for k in ks if "render_kernel" in k]
+    pretty = subprocess.run(["c++filt"] + names, check=True, capture_output=True, text=True).stdout.splitlines()
+    kernels = {}
+    for mangled, p in zip(names, pretty):
+        p = re.sub(r"\(.*$", "", p)
+        p = p[5:] if p.startswith("void ") else p
+        d = census(ks[mangled])
+        d.update(meta.get(mangled, {}))
+        kernels[p] = d
+    path = os.path.join(root, "profiles", "valu_census.json")
+    json.dump({"source_hash": bench.source_hash(), "how": "python tests/probes/isa_census.py --write",
+               "note": "static instruction census of the build's gfx950 assembly, cold paths included; useful_valu_share = 1 - "
+                       "(v_mov + v_cndmask + v_readlane/v_writelane/v_readfirstlane) / VALU", "kernels": kernels}, open(path, "w"), indent=1, sort_keys=True)
+    print(f"wrote {path}: {len(kernels)} kernels")
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['--write']:
+        write_committed_census()
+        sys.exit(0)
     ks, meta = parse(sys.argv[1])
     pats = sys.argv[2:]
     res = {}

@@ -57,6 +57,21 @@ def random_spheres(n, seed=0, split_type=abi.RT_SPLIT_SAH, emissive_every=0, sam
     return sc
 
 
+def skewed_chain_of_spheres(n=64, ratio=1.35, split_type=abi.RT_SPLIT_MIDDLE):
+    """collinear spheres whose positions and radii grow geometrically: every split peels one sphere off the small end, so the
+    reference tree is a chain about n levels deep -- the deepest kind of tree a scene of n primitives can have (the
+    wide-tree stack bound of such a tree is ~1.5 x its two-child depth: csrc/rt_api.cpp falls back to the two-child walk when that
+    does not fit the LDS of a CU)"""
+    sc = SceneDescription(split_type)
+    mats = [sc.lambertian(sc.solid((0.8, 0.3, 0.3)), 0.8), sc.lambertian(sc.solid((0.3, 0.8, 0.3)), 0.8), sc.emissive(sc.solid((1.0, 0.9, 0.8)), 3.0)]
+    x = 1.0
+    for i in range(n):
+        sc.sphere((x, 0.0, 0.0), 0.2 * x, mats[2] if i % 9 == 4 else mats[i % 2])
+        x *= ratio
+    sc.set_sky(sc.lerp((0.5, 0.7, 1.0), (1.0, 1.0, 1.0)), (16, 8))
+    return sc
+
+
 def random_triangle_mesh(n, seed=42, extent=10.0, edge=0.05, emissive_every=1000, split_type=abi.RT_SPLIT_SAH,
                          sampler_res=(100, 100)):
     """The synthetic mesh of BASELINE configs 4/5: centres uniform in [-extent,extent]^3,
