@@ -90,10 +90,11 @@ RT_HD uint32_t rt_mulhi_u32(uint32_t a, uint32_t b)
 RT_HD void rt_philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
 	for (int round = 0; round < 10; ++round) {
-		const uint32_t hi0 = rt_mulhi_u32(0xD2511F53u, c[0]);
-		const uint32_t lo0 = 0xD2511F53u * c[0];
-		const uint32_t hi1 = rt_mulhi_u32(0xCD9E8D57u, c[2]);
-		const uint32_t lo1 = 0xCD9E8D57u * c[2];
+		/* the full 64-bit products: on gfx950 ONE v_mad_u64_u32 each instead of a v_mul_hi_u32 / v_mul_lo_u32 pair */
+		const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c[0];
+		const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c[2];
+		const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+		const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
 		const uint32_t n0 = hi1 ^ c[1] ^ k0;
 		const uint32_t n1 = lo1;
 		const uint32_t n2 = hi0 ^ c[3] ^ k1;

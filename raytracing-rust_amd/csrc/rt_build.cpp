@@ -659,8 +659,10 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		};
 		struct Pending { uint64_t host; uint32_t wide; uint32_t need; };
 		std::vector<Pending> todo;
+		std::vector<uint64_t> wide_host; // the reference node each wide node stands for
 		hs.dev_nodes4.reserve(hs.nodes.size() / 3 + 16);
 		hs.dev_nodes4.emplace_back();
+		wide_host.push_back(0);
 		hs.root4_ref = 0;
 		todo.push_back({0, 0, 0});
 		uint32_t wide_stack = 1;
@@ -740,6 +742,7 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 				if (ch.child[0] >= 0) {
 					const uint32_t w = (uint32_t)hs.dev_nodes4.size();
 					hs.dev_nodes4.emplace_back();
+					wide_host.push_back(kids[k]);
 					dn.child[k] = w;
 					todo.push_back({kids[k], w, need_below});
 				} else {
@@ -753,6 +756,65 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			hs.root4_ref = hs.root_ref;
 		} else {
 			hs.stack_depth = std::max(hs.stack_depth, wide_stack);
+			// ---- layout: a node and the inner child a walk most likely descends into NEXT share one 128-byte line.
+			// The memory system moves 128-byte lines and a wide node is 64 bytes: the other half of a
+			// fetched line is useful only if the same lane wants it in its very next step, while the line is still in
+			// the CU's L1.  Creation order put SIBLINGS side by side, which a depth-first walk reaches a whole subtree
+			// later.  Here lines are (head, favourite): the favourite is the head's inner child of largest surface area
+			// (the likeliest to be hit, and nearest-first descent most often continues into it); every other inner
+			// child, and every inner child of a favourite, heads a line of its own.  Heads without an inner child fill
+			// the tail.  Only indices change: the walk (rt_intersect.h descend4) is untouched.  RT_HIP_WIDE_LAYOUT=0
+			// keeps the creation order (A/B measurements). ----
+			const char *layout_env = std::getenv("RT_HIP_WIDE_LAYOUT");
+			if (!(layout_env && layout_env[0] == '0') && hs.dev_nodes4.size() > 2) {
+				const size_t nw = hs.dev_nodes4.size();
+				std::vector<uint32_t> new_index(nw, 0xFFFFFFFFu), pairs, singles, heads;
+				pairs.reserve(nw);
+				heads.push_back(0u);
+				while (!heads.empty()) {
+					const uint32_t h = heads.back();
+					heads.pop_back();
+					const DevNodeQ4 &hn = hs.dev_nodes4[h];
+					int fav = -1;
+					double best = -1.0;
+					for (int k = 0; k < 4; ++k)
+						if (hn.child[k] != kRefNone && (hn.child[k] & kLeafFlag) == 0u && area(hs.nodes[wide_host[hn.child[k]]]) > best) {
+							best = area(hs.nodes[wide_host[hn.child[k]]]);
+							fav = k;
+						}
+					if (fav < 0) {
+						singles.push_back(h);
+						continue;
+					}
+					const uint32_t f = hn.child[fav];
+					pairs.push_back(h);
+					pairs.push_back(f);
+					for (int k = 3; k >= 0; --k)
+						if (k != fav && hn.child[k] != kRefNone && (hn.child[k] & kLeafFlag) == 0u)
+							heads.push_back(hn.child[k]);
+					const DevNodeQ4 &fn = hs.dev_nodes4[f];
+					for (int k = 3; k >= 0; --k)
+						if (fn.child[k] != kRefNone && (fn.child[k] & kLeafFlag) == 0u)
+							heads.push_back(fn.child[k]);
+				}
+				uint32_t next = 0;
+				for (uint32_t w : pairs)
+					new_index[w] = next++;
+				for (uint32_t w : singles)
+					new_index[w] = next++;
+				if (next == nw) { // (every wide node is reachable from the root exactly once)
+					std::vector<DevNodeQ4> moved(nw);
+					for (size_t w = 0; w < nw; ++w) {
+						DevNodeQ4 dn = hs.dev_nodes4[w];
+						for (int k = 0; k < 4; ++k)
+							if (dn.child[k] != kRefNone && (dn.child[k] & kLeafFlag) == 0u)
+								dn.child[k] = new_index[dn.child[k]];
+						moved[new_index[w]] = dn;
+					}
+					hs.dev_nodes4.swap(moved);
+					hs.root4_ref = new_index[0]; // 0: the root heads the first line
+				}
+			}
 			// exact boxes of the leaves, by first slot
 			hs.leaf_box.assign(n, DevLeafBox{});
 			for (const HostNode &hn : hs.nodes)
