@@ -69,7 +69,7 @@ WORKLOADS = {
                "triangles": 1000000, "extent": 10.0},
     # configs[4] is 4096 spp on 8 GPUs; one GPU's share of it is every 8th tile.  The cost of a sample does not
     # depend on how many follow it, so the timed frame carries 64 of the 4096 passes (about 7 s per step).
-    "mesh10m": {"width": 4096, "height": 4096, "spp": 64, "full_spp": 4096, "seed": 42, "bytes": None, "bound": "hbm",
+    "mesh10m": {"width": 4096, "height": 4096, "spp": 64, "full_spp": 4096, "seed": 42, "bytes": 206415.04, "bound": "hbm",
                 "label": "synthetic 10M random-triangle mesh", "config": "one rank's 1/8 tile shard of BASELINE configs[4]",
                 "triangles": 10000000, "extent": 20.0, "shard": (0, 8), "aspect": 1.0},
 }

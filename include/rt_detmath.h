@@ -336,14 +336,35 @@ RT_HD float rt_powf(float x, float y)
 		return 1.0f;
 	if (x != x || y != y)
 		return x + y; /* NaN */
-	if (x < 0.0f)
-		return rt_bits_f32(0x7FC00000u); /* negative base: NaN for the non-integer exponents of this stage (1/gamma) */
+	/* negative base (and -0): powf is defined for INTEGER exponents -- the sign of the result is the parity of y -- and NaN
+	 * otherwise.  1 / gamma is an integer for gamma = 1, 0.5, 0.25, ...; every float of magnitude >= 2^24 is an even integer. */
+	int negate = 0;
+	if (rt_f32_bits(x) & 0x80000000u) {
+		const float ay = fabsf(y);
+		const int y_is_int = (ay >= 16777216.0f) || (ay == floorf(ay));
+		const int y_is_odd = (ay < 16777216.0f) && y_is_int && (((uint32_t)ay & 1u) != 0u);
+		if (x == -INFINITY)
+			return y > 0.0f ? (y_is_odd ? -INFINITY : INFINITY) : (y_is_odd ? -0.0f : 0.0f);
+		if (y == INFINITY || y == -INFINITY) { /* pow(x, +-inf) looks at |x| only */
+			if (x == -1.0f)
+				return 1.0f;
+			return ((-x > 1.0f) == (y > 0.0f)) ? INFINITY : 0.0f;
+		}
+		if (x == 0.0f)
+			return y > 0.0f ? (y_is_odd ? -0.0f : 0.0f) : (y_is_odd ? -INFINITY : INFINITY);
+		if (!y_is_int)
+			return rt_bits_f32(0x7FC00000u);
+		negate = y_is_odd;
+		x = -x;
+	}
 	if (x == 0.0f)
 		return y > 0.0f ? 0.0f : INFINITY;
 	if (x == INFINITY)
 		return y > 0.0f ? INFINITY : 0.0f;
 	if (y == INFINITY || y == -INFINITY)
 		return ((x > 1.0f) == (y > 0.0f)) ? INFINITY : 0.0f;
+	if (x == 1.0f)
+		return negate ? -1.0f : 1.0f;
 	/* x = m * 2^e, m in [sqrt(1/2), sqrt(2)) */
 	uint32_t bits = rt_f32_bits(x);
 	int e = 0;
@@ -398,7 +419,8 @@ RT_HD float rt_powf(float x, float y)
 	q = fma(q, r, 1.0);
 	q = fma(q, r, 1.0);
 	const double scale = rt_bits_f64((uint64_t)((long long)n + 1023) << 52); /* 2^n, n in [-200, 200] */
-	return (float)(q * scale);
+	const float result = (float)(q * scale);
+	return negate ? -result : result;
 }
 
 /* save_data_to_image's pixel conversion (crates/output/src/lib.rs:92-95): (val.powf(1.0 / gamma) * 255.999) as u8.

@@ -1394,8 +1394,22 @@ __global__ __launch_bounds__(256) void quantise_kernel(const float *__restrict__
 	if (blockIdx.x == 0 && threadIdx.x < (n_values & 3))
 		out[n4 * 4 + threadIdx.x] = rt_quantise_u8(rgb[n4 * 4 + threadIdx.x], inv_gamma);
 }
+// ... and for caller-supplied pointers that are not 16-byte (input) / 4-byte (output) aligned, e.g. a view into a larger
+// buffer at an odd offset: one value per lane
+__global__ __launch_bounds__(256) void quantise_unaligned_kernel(const float *__restrict__ rgb, size_t n_values, float inv_gamma, uint8_t *__restrict__ out)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride)
+		out[i] = rt_quantise_u8(rgb[i], inv_gamma);
+}
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out)
 {
+	if ((reinterpret_cast<uintptr_t>(rgb) & 15u) != 0u || (reinterpret_cast<uintptr_t>(out) & 3u) != 0u) {
+		size_t blocks = (n_values + 255) / 256;
+		blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+		hipLaunchKernelGGL(quantise_unaligned_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, rgb, n_values, inv_gamma, out);
+		return hipGetLastError();
+	}
 	size_t blocks = (n_values / 4 + 255) / 256;
 	if (blocks < 1)
 		blocks = 1;

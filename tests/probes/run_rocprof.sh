@@ -3,6 +3,7 @@
 #   tests/probes/run_rocprof.sh <tag> [workload] [steps for the stats run]  -> gpurun_out/prof_<tag>/{trace,pmc_*}/...
 # kernel-trace + stats in one run; every PMC set in its own run (no other trace domains), as
 # MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')  # the interpreter itself: no shim / wrapper exec after the profiler has initialised the GPU
 set -o pipefail
 TAG=${1:-r02}
 WL=${2:-rtweekend1}
@@ -14,10 +15,10 @@ export TMPDIR=/tmp
 cd /tmp
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())" > $OUT/source_hash.txt
 echo "$WL" > $OUT/workload.txt
-BENCH="python3 $R/bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-walk-stats"
-echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-walk-stats (stats); rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-walk-stats (one run per set)" > $OUT/command.txt
+BENCH="$PY $R/bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-walk-stats"
+echo "interpreter: $PY; rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline --no-walk-stats (stats); rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-walk-stats (one run per set)" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err || exit 1
-BENCH1="python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-walk-stats"
+BENCH1="$PY $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-walk-stats"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum" \

@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC + stats for an arbitrary command: tests/probes/run_rocprof_cmd.sh <tag> <python-script-and-args...>
+PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')  # the interpreter itself: no shim / wrapper exec after the profiler has initialised the GPU
 set -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,8 +8,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python3 $R/$*"
-echo "rocprofv3 --kernel-trace --stats -- python3 $* (stats); rocprofv3 --pmc <set> --kernel-trace -- python3 $* (one run per set)" > $OUT/command.txt
+CMD="$PY $R/$*"
+echo "interpreter: $PY; rocprofv3 --kernel-trace --stats -- python3 $* (stats); rocprofv3 --pmc <set> --kernel-trace -- python3 $* (one run per set)" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.out 2> $OUT/trace.err || exit 1
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
