@@ -105,6 +105,17 @@ __device__ __forceinline__ bool aabb_does_int(const float bmin[3], const float b
 	return tmax > fmax_(tmin, 0.0f);
 }
 
+// sqrtf; the short form of rt_lean.h where the argument is in its range (>= 2^-96; zero, negatives and NaN too), the plain
+// operator for the tiny positives in between
+__device__ __forceinline__ float sqrt_from_(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_LEAN)
+	if (__builtin_expect(!(x < kLeanSqrtMin) || !(x > 0.0f), 1))
+		return lean_sqrt(x);
+#endif
+	return sqrtf(x);
+}
+
 // Sphere::get_int up to the choice of t  sphere.rs:34-77
 __device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray &r, float &t)
 {
@@ -115,7 +126,7 @@ __device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray &r, 
 	const float discriminant = radius * radius - dot(remedy_term, remedy_term);
 	if (!(discriminant > 0.0f))
 		return false;
-	const float sqrt_val = sqrtf(discriminant);
+	const float sqrt_val = sqrtf(discriminant); // (the tested short form, sqrt_from_, measured no gain here: its branch costs what it saves)
 	const float q = ddp > 0.0f ? ddp + sqrt_val : ddp - sqrt_val;
 	float t0 = q;
 	float t1 = (deltapdot - radius * radius) / q;
@@ -228,6 +239,9 @@ template <class F> __device__ __forceinline__ bool prim_t(const PrimGeom &g, con
 struct Hit {
 	float t;
 	V3 point, error, normal;
+	// dot(|normal|, error): all that offset_ray (utility/mod.rs:88-117) ever reads of `error`.  Formed once where the hit is
+	// made, so the paths carry one register from bounce to bounce instead of three (same operands, same operation: same bits)
+	float err_dot;
 	float uvx, uvy;
 	bool has_uv, out;
 };
@@ -263,6 +277,7 @@ template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, u
 		h.point = point;
 		h.error = kEpsilon * v3s(1.0f);
 		h.normal = normal;
+		h.err_dot = dot(vabs(normal), h.error);
 		h.uvx = h.uvy = 0.0f;
 		h.has_uv = false; // no material overrides Scatter::requires_uv (rt_core/src/material.rs:8-10)
 		h.out = out;
@@ -281,6 +296,7 @@ template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, u
 	h.point = b0 * g.p0 + b1 * g.p1 + b2 * g.p2;
 	h.error = gamma_n(7) * v3(x_abs_sum, y_abs_sum, z_abs_sum) + gamma_n(6) * v3(b2 * g.p2.x, b2 * g.p2.y, b2 * g.p2.z);
 	h.normal = normal;
+	h.err_dot = dot(vabs(normal), h.error);
 	h.uvx = b0 * 0.0f + b1 * 1.0f + b2 * 1.0f; // b0*(0,0) + b1*(1,0) + b2*(1,1)
 	h.uvy = b0 * 0.0f + b1 * 0.0f + b2 * 1.0f;
 	h.has_uv = true;
@@ -292,6 +308,7 @@ __device__ __forceinline__ void make_sky_hit(const DevScene &S, Hit &h, uint32_t
 {
 	h.t = 0.0f;
 	h.point = h.error = h.normal = v3s(0.0f);
+	h.err_dot = 0.0f;
 	h.uvx = h.uvy = 0.0f;
 	h.has_uv = false;
 	h.out = false;

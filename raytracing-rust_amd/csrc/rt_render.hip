@@ -315,6 +315,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	Hit hit;
 	hit.t = 0.0f;
 	hit.point = hit.error = hit.normal = v3s(0.0f);
+	hit.err_dot = 0.0f;
 	hit.uvx = hit.uvy = 0.0f;
 	hit.has_uv = hit.out = false;
 	uint32_t mat = 0;
@@ -779,6 +780,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		hit.point = v3(__uint_as_float(a3.z), __uint_as_float(a3.w), __uint_as_float(a4.x));
 		hit.error = v3(__uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
 		hit.normal = v3(__uint_as_float(a5.x), __uint_as_float(a5.y), __uint_as_float(a5.z));
+		hit.err_dot = dot(vabs(hit.normal), hit.error); // (not part of the record: re-formed from what is)
 		hit.uvx = __uint_as_float(a5.w);
 		hit.uvy = __uint_as_float(a6.x);
 		hit.has_uv = (a6.y & 1u) != 0u; hit.out = (a6.y & 2u) != 0u; primary = (a6.y & 4u) != 0u;
@@ -971,6 +973,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			hit.point = v3(__uint_as_float(a3.z), __uint_as_float(a3.w), __uint_as_float(a4.x));
 			hit.error = v3(__uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
 			hit.normal = v3(__uint_as_float(a5.x), __uint_as_float(a5.y), __uint_as_float(a5.z));
+		hit.err_dot = dot(vabs(hit.normal), hit.error); // (not part of the record: re-formed from what is)
 			hit.uvx = __uint_as_float(a5.w);
 			hit.uvy = __uint_as_float(a6.x);
 			hit.has_uv = (a6.y & 1u) != 0u; hit.out = (a6.y & 2u) != 0u; primary = (a6.y & 4u) != 0u;

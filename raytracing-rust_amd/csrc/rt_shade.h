@@ -50,9 +50,9 @@ __device__ __forceinline__ float previous_float(float f) // :67-81
 	const uint32_t bits = __float_as_uint(f);
 	return __uint_as_float(f <= 0.0f ? bits + 1u : bits - 1u);
 }
-__device__ __forceinline__ V3 offset_ray(V3 origin, V3 normal, V3 error, bool is_brdf) // :88-117
+// offset_ray(origin, normal, error, is_brdf) with offset_val = dot(|normal|, error) already formed (Hit::err_dot)
+__device__ __forceinline__ V3 offset_ray(V3 origin, V3 normal, float offset_val, bool is_brdf) // :88-117
 {
-	const float offset_val = dot(vabs(normal), error);
 	V3 offset = offset_val * normal;
 	if (!is_brdf)
 		offset = -offset;
@@ -386,7 +386,7 @@ template <class F> __device__ __forceinline__ bool reflect_scatter(float fuzz, R
 {
 	V3 direction = -ray.d;
 	direction = reflected(direction, hit.normal);
-	const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+	const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
 	const V3 ruv = random_unit_vector(rng);
 	ray = ray_new<F>(point, direction + fuzz * ruv);
 	return false;
@@ -399,7 +399,7 @@ template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScen
 	const int type = m.type;
 	if (type == 1) { // Lambertian  lambertian.rs:30-41
 		const V3 direction = lambertian_sample(hit.normal, rng);
-		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
 		ray = ray_new<F>(point, direction);
 		return false;
 	}
@@ -423,13 +423,13 @@ template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScen
 			return reflect_scatter<F>(0.0f, ray, hit, rng);
 		const V3 perp = eta_fraction * (ray.d + cos_theta * hit.normal);
 		const V3 para = (-1.0f * sqrtf(fabsf(1.0f - mag_sq(perp)))) * hit.normal;
-		const V3 point = offset_ray(hit.point, hit.normal, hit.error, false);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, false);
 		ray = ray_new<F>(point, perp + para);
 		return false;
 	}
 	if (type == 2) { // TrowbridgeReitz  trowbridge_reitz.rs:38-51
 		const V3 direction = tr_sample(m.param, -ray.d, hit.normal, rng);
-		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
 		ray = ray_new<F>(point, direction);
 		return false;
 	}
@@ -494,7 +494,7 @@ template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene
 {
 	const DevMaterial &m = S.materials[mat];
 	if (m.type == 0) { // emissive.rs:23-26
-		const V3 point = offset_ray(hit.point, hit.normal, hit.error, true);
+		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
 		return m.param * material_texture_colour<F>(S, m, wo, point);
 	}
 	return v3s(0.0f);
@@ -523,16 +523,18 @@ template <class F> __device__ inline V3 prim_sample_visible_from_point(const Pri
 			lean_sincos(b, sin_b, cos_b);
 			point = center + radius * v3(a * cos_b, a * sin_b, z);
 		} else {
-			const float distance = sqrtf(distance_sq);
+			// (max(1 - x, 0) of a float x: zero, NaN or at least 2^-24 -- inside the short square root's range, rt_lean.h;
+			// the other arguments are tested)
+			const float distance = sqrt_from_(distance_sq);
 			const float sin_theta_max_sq = radius * radius / distance_sq;
-			const float cost_theta_max = sqrtf(fmax_(1.0f - sin_theta_max_sq, 0.0f));
+			const float cost_theta_max = sqrt_unit_(fmax_(1.0f - sin_theta_max_sq, 0.0f));
 			const float r1 = rt_rng_f32(&rng);
 			const float cos_theta = (1.0f - r1) + r1 * cost_theta_max;
-			const float sin_theta = sqrtf(fmax_(1.0f - cos_theta * cos_theta, 0.0f));
+			const float sin_theta = sqrt_unit_(fmax_(1.0f - cos_theta * cos_theta, 0.0f));
 			const float phi = 2.0f * rt_rng_f32(&rng) * kPi;
-			const float ds = distance * cos_theta - sqrtf(fmax_(radius * radius - distance_sq * sin_theta * sin_theta, 0.0f));
+			const float ds = distance * cos_theta - sqrt_from_(fmax_(radius * radius - distance_sq * sin_theta * sin_theta, 0.0f));
 			const float cos_alpha = (distance_sq + radius * radius - ds * ds) / (2.0f * distance * radius);
-			const float sin_alpha = sqrtf(fmax_(1.0f - cos_alpha * cos_alpha, 0.0f));
+			const float sin_alpha = sqrt_unit_(fmax_(1.0f - cos_alpha * cos_alpha, 0.0f));
 			const Coord cs = coord_from_z(normalised(in_point - center));
 			float sin_phi, cos_phi;
 			lean_sincos(phi, sin_phi, cos_phi);
@@ -559,7 +561,7 @@ template <class F> __device__ __forceinline__ float prim_scattering_pdf(const Pr
 		if (dsq <= rsq)
 			return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(wi, sampled_hit.normal)) * prim_area<F>(g));
 		const float sin_theta_max_sq = rsq / dsq;
-		const float cos_theta_max = sqrtf(fmax_(1.0f - sin_theta_max_sq, 0.0f));
+		const float cos_theta_max = sqrt_unit_(fmax_(1.0f - sin_theta_max_sq, 0.0f));
 		return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));
 	}
 	return mag_sq(sampled_hit.point - hit_point) / (fabsf(dot(sampled_hit.normal, wi)) * prim_area<F>(g));
