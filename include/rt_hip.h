@@ -278,6 +278,9 @@ int rt_scene_get_lights(const rt_scene *scene, uint64_t *out, uint64_t capacity)
  * child: bit 31 set = leaf (bits 26-30 primitive count or 0 = big leaf, bits 0-25 first slot), 0x7FFFFFFE = absent,
  * otherwise a wide-node index; root_ref in the same encoding; stack_depth = traversal stack entries the scene needs.
  * n_wide_nodes = 0: no wide tree (non-finite or huge bounds, or a single leaf). */
+/* (This is the EXPLICIT form, for inspection.  The kernels fetch a compact re-encoding of the same nodes -- inner children are
+ * consecutive nodes, leaf children consecutive leaf indices, so the four references fold into two words and a node step reads
+ * 48 bytes instead of 64; every node is decoded back to this form when the scene is built: csrc/rt_types.h, csrc/rt_build.cpp.) */
 int rt_scene_wide_info(const rt_scene *scene, uint64_t *n_wide_nodes, uint32_t *root_ref, uint32_t *stack_depth);
 int rt_scene_get_wide_nodes(const rt_scene *scene, void *out, uint64_t capacity_nodes);
 /* exact leaf boxes of the wide walk, one { float lo[3], pad, hi[3], pad } per primitive slot (meaningful at the first

@@ -247,8 +247,9 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 	}
 	if ((rc = upload(s, h.dev_nodes.data(), h.dev_nodes.size(), &D.nodes)) != RT_OK) return bail(rc);
 	if (!h.dev_nodes4.empty()) { // hipMalloc aligns far beyond the 128 bytes a DevNode4 line needs
-		if ((rc = upload(s, h.dev_nodes4.data(), h.dev_nodes4.size(), &D.nodes4)) != RT_OK) return bail(rc);
-		if ((rc = upload(s, h.leaf_box.data(), h.leaf_box.size(), &D.leaf_box)) != RT_OK) return bail(rc);
+		// (the compact form: rt_types.h; rt_scene_get_wide_nodes / rt_scene_get_leaf_boxes show the explicit one)
+		if ((rc = upload(s, h.dev_nodes4c.data(), h.dev_nodes4c.size(), &D.nodes4)) != RT_OK) return bail(rc);
+		if ((rc = upload(s, h.leaf_box_c.data(), h.leaf_box_c.size(), &D.leaf_box)) != RT_OK) return bail(rc);
 	}
 	if ((rc = upload(s, h.dev_prims.data(), h.dev_prims.size(), &D.prims)) != RT_OK) return bail(rc);
 	if ((rc = upload(s, h.dev_shade.data(), h.dev_shade.size(), &D.shade)) != RT_OK) return bail(rc);

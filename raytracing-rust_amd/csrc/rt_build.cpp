@@ -647,6 +647,8 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 	// bounds and inverse directions to stay finite). ----
 	hs.dev_nodes4.clear();
 	hs.leaf_box.clear();
+	hs.dev_nodes4c.clear();
+	hs.leaf_box_c.clear();
 	hs.root4_ref = hs.root_ref;
 	bool tame_bounds = true;
 	for (const HostNode &hn : hs.nodes)
@@ -756,65 +758,6 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			hs.root4_ref = hs.root_ref;
 		} else {
 			hs.stack_depth = std::max(hs.stack_depth, wide_stack);
-			// ---- layout: a node and the inner child a walk most likely descends into NEXT share one 128-byte line.
-			// The memory system moves 128-byte lines and a wide node is 64 bytes: the other half of a
-			// fetched line is useful only if the same lane wants it in its very next step, while the line is still in
-			// the CU's L1.  Creation order put SIBLINGS side by side, which a depth-first walk reaches a whole subtree
-			// later.  Here lines are (head, favourite): the favourite is the head's inner child of largest surface area
-			// (the likeliest to be hit, and nearest-first descent most often continues into it); every other inner
-			// child, and every inner child of a favourite, heads a line of its own.  Heads without an inner child fill
-			// the tail.  Only indices change: the walk (rt_intersect.h descend4) is untouched.  RT_HIP_WIDE_LAYOUT=0
-			// keeps the creation order (A/B measurements). ----
-			const char *layout_env = std::getenv("RT_HIP_WIDE_LAYOUT");
-			if (!(layout_env && layout_env[0] == '0') && hs.dev_nodes4.size() > 2) {
-				const size_t nw = hs.dev_nodes4.size();
-				std::vector<uint32_t> new_index(nw, 0xFFFFFFFFu), pairs, singles, heads;
-				pairs.reserve(nw);
-				heads.push_back(0u);
-				while (!heads.empty()) {
-					const uint32_t h = heads.back();
-					heads.pop_back();
-					const DevNodeQ4 &hn = hs.dev_nodes4[h];
-					int fav = -1;
-					double best = -1.0;
-					for (int k = 0; k < 4; ++k)
-						if (hn.child[k] != kRefNone && (hn.child[k] & kLeafFlag) == 0u && area(hs.nodes[wide_host[hn.child[k]]]) > best) {
-							best = area(hs.nodes[wide_host[hn.child[k]]]);
-							fav = k;
-						}
-					if (fav < 0) {
-						singles.push_back(h);
-						continue;
-					}
-					const uint32_t f = hn.child[fav];
-					pairs.push_back(h);
-					pairs.push_back(f);
-					for (int k = 3; k >= 0; --k)
-						if (k != fav && hn.child[k] != kRefNone && (hn.child[k] & kLeafFlag) == 0u)
-							heads.push_back(hn.child[k]);
-					const DevNodeQ4 &fn = hs.dev_nodes4[f];
-					for (int k = 3; k >= 0; --k)
-						if (fn.child[k] != kRefNone && (fn.child[k] & kLeafFlag) == 0u)
-							heads.push_back(fn.child[k]);
-				}
-				uint32_t next = 0;
-				for (uint32_t w : pairs)
-					new_index[w] = next++;
-				for (uint32_t w : singles)
-					new_index[w] = next++;
-				if (next == nw) { // (every wide node is reachable from the root exactly once)
-					std::vector<DevNodeQ4> moved(nw);
-					for (size_t w = 0; w < nw; ++w) {
-						DevNodeQ4 dn = hs.dev_nodes4[w];
-						for (int k = 0; k < 4; ++k)
-							if (dn.child[k] != kRefNone && (dn.child[k] & kLeafFlag) == 0u)
-								dn.child[k] = new_index[dn.child[k]];
-						moved[new_index[w]] = dn;
-					}
-					hs.dev_nodes4.swap(moved);
-					hs.root4_ref = new_index[0]; // 0: the root heads the first line
-				}
-			}
 			// exact boxes of the leaves, by first slot
 			hs.leaf_box.assign(n, DevLeafBox{});
 			for (const HostNode &hn : hs.nodes)
@@ -823,6 +766,68 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 					std::memcpy(b.lo, hn.min, 12);
 					std::memcpy(b.hi, hn.max, 12);
 				}
+			// ---- the compact form the kernels walk (rt_types.h): inner children of a node are consecutive nodes (they were
+			// created so), its leaf children get consecutive LEAF INDICES, and the node stores the two bases, a leaf mask
+			// and a 2-bit offset per child instead of four 32-bit references.  Checked by decoding every node back. ----
+			hs.dev_nodes4c.assign(hs.dev_nodes4.size(), DevNodeQ4{});
+			hs.leaf_box_c.clear();
+			hs.leaf_box_c.reserve(hs.nodes.size() / 2 + 1);
+			for (size_t w = 0; w < hs.dev_nodes4.size() && ok; ++w) {
+				const DevNodeQ4 &src = hs.dev_nodes4[w];
+				DevNodeQ4 dn = src;
+				uint32_t inner_base = 0, n_inner = 0, n_leaf = 0, leaf_mask = 0, deltas = 0;
+				const uint32_t leaf_base = (uint32_t)hs.leaf_box_c.size();
+				for (int k = 0; k < 4; ++k) {
+					const uint32_t c = src.child[k];
+					if (c == kRefNone)
+						continue; // (its stored interval is inverted on every axis: the walk's box test rejects it by itself)
+					if (c & kLeafFlag) {
+						uint32_t first = c & kLeafSlotMask;
+						if (((c >> 26) & 31u) == 0u)
+							first = hs.big_leaves[2 * (size_t)first];
+						DevLeafBox lb = hs.leaf_box[first];
+						std::memcpy(&lb.pad0, &c, 4); // the leaf's own reference: (count, first slot) or a big-leaf index
+						hs.leaf_box_c.push_back(lb);
+						leaf_mask |= 1u << k;
+						deltas |= n_leaf << (2 * k);
+						++n_leaf;
+					} else {
+						if (n_inner == 0)
+							inner_base = c;
+						ok = ok && c == inner_base + n_inner;
+						deltas |= n_inner << (2 * k);
+						++n_inner;
+					}
+				}
+				ok = ok && inner_base < (1u << 26) && leaf_base + n_leaf < (1u << 26);
+				dn.exps = (src.exps & 0x00FFFFFFu) | (deltas << 24);
+				dn.child[0] = inner_base | (leaf_mask << 26);
+				dn.child[1] = leaf_base;
+				dn.child[2] = dn.child[3] = 0u; // (never fetched)
+				hs.dev_nodes4c[w] = dn;
+				for (int k = 0; k < 4 && ok; ++k) { // decode as the kernel does (rt_intersect.h wide_child_ref) and compare
+					const uint32_t c = src.child[k];
+					if (c == kRefNone)
+						continue;
+					const uint32_t delta = (dn.exps >> (24 + 2 * k)) & 3u;
+					const bool is_leaf = ((dn.child[0] >> (26 + k)) & 1u) != 0u;
+					if (is_leaf) {
+						uint32_t back;
+						std::memcpy(&back, &hs.leaf_box_c[(dn.child[1] & kLeafSlotMask) + delta].pad0, 4);
+						ok = ok && back == c;
+					} else {
+						ok = ok && (dn.child[0] & kLeafSlotMask) + delta == c;
+					}
+				}
+			}
+			if (!ok) { // cannot happen; never ship a tree that does not decode to itself
+				hs.dev_nodes4.clear();
+				hs.dev_nodes4c.clear();
+				hs.leaf_box.clear();
+				hs.leaf_box_c.clear();
+				hs.root4_ref = hs.root_ref;
+				hs.stack_depth = hs.stack_depth_narrow;
+			}
 		}
 	}
 	if (hs.stack_depth > 96) {

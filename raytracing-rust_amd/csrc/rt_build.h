@@ -24,8 +24,13 @@ struct HostScene {
 	std::vector<uint64_t> lights;          // Bvh.lights (slots)
 	// device images
 	std::vector<DevNode> dev_nodes;
-	std::vector<DevNodeQ4> dev_nodes4; // wide tree (empty: not built)
-	std::vector<DevLeafBox> leaf_box;  // exact leaf boxes by first slot (only with the wide tree)
+	std::vector<DevNodeQ4> dev_nodes4; // wide tree with explicit child references (empty: not built): what rt_scene_get_wide_nodes shows
+	std::vector<DevLeafBox> leaf_box;  // exact leaf boxes by first slot (only with the wide tree): what rt_scene_get_leaf_boxes shows
+	// ... and as the kernels read it (rt_types.h "compact wide node"): the same nodes with the four child references folded into
+	// two words, so a node step fetches three 16-byte pieces instead of four, and the leaf boxes by LEAF INDEX, each carrying
+	// its leaf's (first slot, count) reference
+	std::vector<DevNodeQ4> dev_nodes4c;
+	std::vector<DevLeafBox> leaf_box_c;
 	uint32_t root4_ref = 0;
 	std::vector<DevPrim> dev_prims;
 	std::vector<DevShade> dev_shade;

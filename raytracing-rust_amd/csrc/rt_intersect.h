@@ -484,7 +484,7 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
                                              float t_limit)
 {
 	const uint4 *q = reinterpret_cast<const uint4 *>(&S.nodes4[node]);
-	const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	const uint4 q0 = q[0], q1 = q[1], q2 = q[2]; // the compact node: three pieces (rt_types.h)
 	const float sx = __uint_as_float((q0.w & 0xFFu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xFFu) << 23),
 	            sz = __uint_as_float(((q0.w >> 16) & 0xFFu) << 23);
 	const float ax = sx * r.inv.x, ay = sy * r.inv.y, az = sz * r.inv.z; // exact: the steps are powers of two
@@ -502,7 +502,6 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 	// slack of the two-child walk (kPruneSlack, with the node's whole extent standing in for the child's)
 	const float ext = 255.0f * (sx + sy + sz);
 	const float cut = (PRUNE && limit_valid) ? t_limit + kPruneSlack * (fabsf(t_limit) + ext) : INFINITY;
-	const uint32_t ref[4] = {q2.z, q2.w, q3.x, q3.y};
 	uint32_t key[4]; // entry distance as ordered bits with the child slot in the two low bits; 0xFFFFFFFF = do not visit
 #pragma unroll
 	for (int c = 0; c < 4; ++c) {
@@ -512,13 +511,19 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 		const float tf = fminf(fminf(fmaf((float)((fx >> sh) & 0xFFu), ax, bx), fmaf((float)((fy >> sh) & 0xFFu), ay, by)),
 		                       fmaf((float)((fz >> sh) & 0xFFu), az, bz));
 		const float te = fmaxf(tn - pad, 0.0f);
-		const bool h = ref[c] != kRefNone && (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut);
+		const bool h = (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut); // (an absent child's interval is inverted: tf - tn = -255 |a|)
 		key[c] = h ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
 	}
 #define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }
 	RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-	auto ref_of = [&](uint32_t k) { const uint32_t c = k & 3u; return c == 0u ? ref[0] : (c == 1u ? ref[1] : (c == 2u ? ref[2] : ref[3])); };
+	// child c of the compact node: inner node q2.z + offset or leaf index q2.w + offset, by bit c of the leaf mask
+	auto ref_of = [&](uint32_t k) {
+		const uint32_t c = k & 3u;
+		const uint32_t delta = (q0.w >> (24u + 2u * c)) & 3u;
+		const bool is_leaf = ((q2.z >> (26u + c)) & 1u) != 0u;
+		return is_leaf ? (kLeafFlag | ((q2.w & kLeafSlotMask) + delta)) : ((q2.z & kLeafSlotMask) + delta);
+	};
 	if (key[0] == 0xFFFFFFFFu) { // nothing to descend into: back to the nearest pending sibling
 		if (sp == 0)
 			return kRefDone;
@@ -531,14 +536,14 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 	return ref_of(key[0]);
 }
 
-// the candidate test of the wide walk: does the ray hit this leaf's EXACT reference box (reference predicate)?
-__device__ __forceinline__ bool leaf_box_hit(const DevScene &S, uint32_t leaf, const Ray &r)
+// the candidate test of the wide walk: does the ray hit this leaf's EXACT reference box (reference predicate)?  `leaf` is
+// a wide-tree leaf reference (kLeafFlag | leaf index); `ref` receives the leaf's own reference -- (count, first slot) or a
+// big-leaf index, what leaf_range / closest_in_leaf / any_in_leaf take -- from the spare word of the box record
+__device__ __forceinline__ bool wide_leaf_hit(const DevScene &S, uint32_t leaf, const Ray &r, uint32_t &ref)
 {
-	uint32_t first = leaf & kLeafSlotMask;
-	if (((leaf >> 26) & 31u) == 0u)
-		first = S.big_leaves[first].x;
-	const float4 *q = reinterpret_cast<const float4 *>(&S.leaf_box[first]);
+	const float4 *q = reinterpret_cast<const float4 *>(&S.leaf_box[leaf & kLeafSlotMask]);
 	const float4 a = q[0], b = q[1];
+	ref = __float_as_uint(a.w);
 	const float lo[3] = {a.x, a.y, a.z}, hi[3] = {b.x, b.y, b.z};
 	float t;
 	return aabb_does_int(lo, hi, r, t);
@@ -634,8 +639,9 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 			            : descend<PRUNE, OVF>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t);
 		if (node == kRefDone)
 			break;
-		if (!wide || leaf_box_hit(S, node, r))
-			closest_in_leaf<F>(S, r, node, best_t, best_prim);
+		uint32_t leaf = node;
+		if (!wide || wide_leaf_hit(S, node, r, leaf))
+			closest_in_leaf<F>(S, r, leaf, best_t, best_prim);
 		if (sp == 0)
 			break;
 		--sp;
@@ -675,7 +681,8 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 			            : descend<PRUNE, OVF>(S, M, r, node, stk, sp, limited, t_limit);
 		if (node == kRefDone)
 			break;
-		if ((!wide || leaf_box_hit(S, node, r)) && any_in_leaf<F>(S, r, node, t_limit, skip))
+		uint32_t leaf = node;
+		if ((!wide || wide_leaf_hit(S, node, r, leaf)) && any_in_leaf<F>(S, r, leaf, t_limit, skip))
 			return true;
 		if (sp == 0)
 			break;

@@ -455,11 +455,12 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 
 	// LEAF -- one leaf: the primitive loops of Bvh::check_hit (mod.rs:270-293) / check_hit_index (:244-261)
 	auto do_leaf = [&]() {
-		uint32_t first, count;
-		leaf_range(S, node, first, count);
+		uint32_t first, count, leaf_ref;
 		// the walk got here through conservative boxes: the leaf is a candidate iff its exact box passes the
-		// reference's test (rt_intersect.h, the wide walk)
-		if (!leaf_box_hit(S, node, ray))
+		// reference's test (rt_intersect.h, the wide walk); the box record also says which primitives the leaf holds
+		const bool candidate = wide_leaf_hit(S, node, ray, leaf_ref);
+		leaf_range(S, leaf_ref, first, count);
+		if (!candidate)
 			count = 0u;
 		bool occluded = false;
 		for (uint32_t slot = first; slot < first + count; ++slot) {
@@ -1626,8 +1627,9 @@ __global__ __launch_bounds__(256, WAVES) void trace_queue_kernel(const DevScene 
 		}
 		if (c_leaf >= kDrainLanes || c_node == 0u) {
 			if (ph == LEAF) {
-				if (leaf_box_hit(S, node, ray))
-					closest_in_leaf<F>(S, ray, node, best_t, best_prim);
+				uint32_t leaf_ref;
+				if (wide_leaf_hit(S, node, ray, leaf_ref))
+					closest_in_leaf<F>(S, ray, leaf_ref, best_t, best_prim);
 				if (sp == 0) {
 					finish();
 				} else {

@@ -54,6 +54,14 @@ static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 // only decide where the walk goes; whether a leaf's primitives are tested is decided by the leaf's EXACT reference
 // box (DevScene::leaf_box) and the reference's own predicate.  Why that returns the reference's hits: rt_intersect.h.
 // Absent children have child == kRefNone.
+// COMPACT FORM (what the kernels fetch; rt_build.cpp encodes it from the explicit form above and decodes every node back as a
+// check): the inner children of a node are consecutive nodes and its leaf children consecutive LEAF INDICES, so the four
+// references fold into   child[0] = first inner child | leaf mask << 26   child[1] = first leaf index
+// and a 2-bit offset per child in the top byte of `exps` (child k is inner node child[0] + offset_k or leaf child[1] +
+// offset_k by bit k of the mask).  A node step then needs only the first THREE 16-byte pieces of the record -- the walk
+// is bound by the number of such pieces its lanes fetch -- and a leaf's (first slot, count) reference
+// rides in the spare word of its exact box (DevLeafBox::ref), which the walk fetches anyway before it touches a primitive.
+// An absent child needs no flag: its stored interval is inverted on every axis, so the walk's own box test rejects it.
 constexpr uint32_t kRefNone = 0x7FFFFFFEu;
 struct alignas(64) DevNodeQ4 {
 	float origin[3];     // lower corner of the node's grid
@@ -65,7 +73,8 @@ struct alignas(64) DevNodeQ4 {
 };
 static_assert(sizeof(DevNodeQ4) == 64, "DevNodeQ4 must be one 64-byte record");
 
-// exact reference box of a leaf, indexed by the leaf's FIRST primitive slot (32-byte stride: two dwordx4)
+// exact reference box of a leaf (32-byte stride: two dwordx4), indexed by the leaf's index in the wide tree; pad0 carries the
+// leaf's reference (kLeafFlag | count << 26 | first slot, or a big-leaf index) as a bit pattern
 struct alignas(32) DevLeafBox {
 	float lo[3], pad0;
 	float hi[3], pad1;
@@ -144,7 +153,7 @@ struct DevScene {
 	uint32_t off_nodes, off_prims, off_shade, off_rank, off_materials, off_textures, off_lights, off_big_leaves;
 	uint32_t stack_depth;      // traversal stack entries per lane (enough for the two-child AND the wide walk)
 	const DevNodeQ4 *nodes4;   // wide tree (null: none was built, e.g. non-finite bounds)
-	const DevLeafBox *leaf_box; // exact leaf boxes for the wide walk, by first primitive slot
+	const DevLeafBox *leaf_box; // exact leaf boxes (+ leaf references) for the wide walk, by leaf index
 	uint32_t root4_ref;        // child-style reference to its root
 	uint32_t n_nodes4;
 	uint32_t narrow_only;      // RT_TUNE_WALK = 1: every ray takes the two-child walk (tests, A/B measurements)
