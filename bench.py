@@ -466,9 +466,11 @@ def main():
             # the shading code), which moving path state between lanes cannot touch.
             roof["phase_participation"] = dict(ws, note="lanes of 64 holding a path that takes part in the voted super-phase, -DRT_STATS build, untimed pass")
         if ws and "node_steps_per_sample" in ws:
-            wb = ws["node_steps_per_sample"] * 64 + ws["primitive_tests_per_sample"] * 48
+            # a node step fetches the first 48 bytes of a 64-byte wide-node record (the compact node of round 3: three
+            # 16-byte pieces; rounds 1-2 fetched all 64), a primitive test one 48-byte record
+            wb = ws["node_steps_per_sample"] * 48 + ws["primitive_tests_per_sample"] * 48
             roof["pruned_walk"] = dict(ws, bytes_per_sample=wb, requested_GBps=wb * launch_samples / k_s / 1e9,
-                                       note="counted by the -DRT_STATS build on an untimed pass: 64 B per node step + 48 B per primitive test")
+                                       note="counted by the -DRT_STATS build on an untimed pass: 48 B per node step + 48 B per primitive test")
         if w["bound"] == "hbm":
             wb = roof.get("pruned_walk", {}).get("bytes_per_sample")
             achieved = wb * launch_samples / k_s / 1e9 if wb else None
@@ -480,9 +482,10 @@ def main():
                          "fabric_frac_of_achievable": measured / HBM_ACHIEVABLE_GBS if measured else None,
                          "l2_hit_rate": counters.get("l2_hit_rate"),
                          "lane_utilisation": counters.get("valu_lane_utilisation"),
-                         "note": "achieved = bytes the pruned walk REQUESTS (64 B/node step + 48 B/primitive test, counted live) / kernel time; "
+                         "note": "achieved = bytes the pruned walk REQUESTS (48 B/node step + 48 B/primitive test, counted live) / kernel time; "
                                  "fabric_GBps_from_pmc = what crossed the fabric (Infinity Cache + HBM, 128-byte lines) in the committed profile "
-                                 "of this build: above the requested bytes because a 64-byte node uses half of the line it arrives in"})
+                                 "of this build: above the requested bytes because a node step uses 48 bytes of the 128-byte line it arrives in "
+                                 "(the line count, not the byte count, is what HBM serves: fabric_frac_of_achievable is the saturation figure)"})
         ab = w["bytes"]
         ap = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")  # the oracle's own count, when it has been made for this workload
         if os.path.exists(ap):

@@ -1,10 +1,14 @@
 // host_demo.cpp -- a compiled host above the C ABI: builds scenes/rtweekend1.ssml's content through
 // rt_hip.hpp, renders it with HipSampler::sample_image + the running-mean callback, writes the mean
 // image as raw f32 (and a PNG through the output stage).  Driven by tests/test_gpu_parity.py.
-//   host_demo <out.f32> <out.png> <width> <height> <spp> <batch>
+//   host_demo <out.f32> <out.png> <width> <height> <spp> <batch> [device,device,...]
+// With a device list the Bvh is replicated over those GPUs (rt_scene_create_multi) and every batch is rendered by all of them.
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cstring>
+#include <vector>
+#include <memory>
 
 #include "rt_hip.hpp"
 
@@ -24,7 +28,15 @@ int main(int argc, char **argv)
 		scene.sphere({0.0f, 1.0f, -100.5f}, 100.0f, ground);
 		scene.sphere({0.0f, 1.0f, 0.0f}, 0.5f, ground);
 		scene.sky(sky_tex, 100, 100);
-		Bvh bvh(scene, SplitType::Sah, 0);
+		std::vector<int> devices;
+		if (argc > 7)
+			for (const char *p = argv[7]; *p;) {
+				devices.push_back((int)std::strtol(p, const_cast<char **>(&p), 10));
+				if (*p == ',')
+					++p;
+			}
+		std::unique_ptr<Bvh> owned(devices.empty() ? new Bvh(scene, SplitType::Sah, 0) : new Bvh(scene, devices));
+		Bvh &bvh = *owned;
 		SimpleCamera camera({0, 0, 0}, {0, 1, 0}, {0, 0, 1}, 121.28449291441745f, 16.0f / 9.0f, 0.0f, 1.0f);
 
 		RenderOptions o;
@@ -40,6 +52,7 @@ int main(int argc, char **argv)
 			++calls;
 			return running_mean(p, prev, i);
 		});
+		std::printf("devices %u ", bvh.device_count());
 		std::printf("nodes %llu lights %zu calls %d samples %llu rays %llu\n", (unsigned long long)bvh.number_nodes(), bvh.lights().size(),
 		            calls, (unsigned long long)image.sampler_progress.samples_completed, (unsigned long long)image.sampler_progress.rays_shot);
 		FILE *f = std::fopen(argv[1], "wb");
