@@ -1245,15 +1245,31 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				}
 	#endif
 				RT_SECTION(0); // vote + work acquisition
+				// ONE divergent region per super-phase (a lane that generates a sample also walks and shades it, so the lanes that
+				// sit the phase out are merged back once, not after every step: fewer copies of path state) for the spheres-only
+				// kernels: config 2 28.46 -> 28.02 ms at 256 spp, same box, three rounds.  The simple / full variants keep one region
+				// per step: fused, config 3 measured 42.3 -> 43.3 ms (their spilled registers move into the longer region).
+				constexpr bool kFuseRegions = METHOD == 1 && RT_PQ_SPLIT && KernelShape<F>::spheres_only;
 				if (!run_light) {
-					if (ph == PH_GEN)
-						do_gen();
-					RT_SECTION(1);
-					walk_closest_pending();
-					RT_SECTION(2);
-					if (ph == PH_SHADE)
-						do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
-					RT_SECTION(3);
+					if (kFuseRegions) {
+						if (ph == PH_GEN) {
+							do_gen();
+							RT_SECTION(1);
+							walk_closest_pending();
+							RT_SECTION(2);
+							do_shade(std::integral_constant<int, 1>{});
+						}
+						RT_SECTION(3);
+					} else {
+						if (ph == PH_GEN)
+							do_gen();
+						RT_SECTION(1);
+						walk_closest_pending();
+						RT_SECTION(2);
+						if (ph == PH_SHADE)
+							do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
+						RT_SECTION(3);
+					}
 				} else {
 					LightCtx L; // loop-local: see LightCtx above
 					L.l_wi = v3s(0.0f);
@@ -1263,23 +1279,40 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 					L.have_shadow = L.shadow_is_sky = false;
 					Ray sray;
 					sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
-					if (ph == PH_LIGHT)
-						do_light(L, sray);
-					RT_SECTION(4);
-					walk_shadow_pending(L, sray);
-					RT_SECTION(5);
-					if (ph == PH_SCATTER)
-						do_scatter(L, sray);
-					RT_SECTION(6);
+					if (kFuseRegions) {
+						if (ph == PH_LIGHT) {
+							do_light(L, sray);
+							RT_SECTION(4);
+							walk_shadow_pending(L, sray);
+							RT_SECTION(5);
+							do_scatter(L, sray);
+							RT_SECTION(6);
+							if (ph == PH_NODE) { // the path goes on: its walk and the bounce arm of SHADE, in the same iteration
+								walk_closest_pending();
+								RT_SECTION(7);
+								do_shade(std::integral_constant<int, 2>{});
+							}
+						}
+						RT_SECTION(8);
+					} else {
+						if (ph == PH_LIGHT)
+							do_light(L, sray);
+						RT_SECTION(4);
+						walk_shadow_pending(L, sray);
+						RT_SECTION(5);
+						if (ph == PH_SCATTER)
+							do_scatter(L, sray);
+						RT_SECTION(6);
 	#if RT_PQ_SPLIT
-					// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
-					// the other super-phase only ever holds primary lanes and neither arm runs half empty
-					walk_closest_pending();
-					RT_SECTION(7);
-					if (ph == PH_SHADE)
-						do_shade(std::integral_constant<int, 2>{});
-					RT_SECTION(8);
+						// the scattered ray's closest walk and the bounce arm of SHADE ride in the same iteration, so
+						// the other super-phase only ever holds primary lanes and neither arm runs half empty
+						walk_closest_pending();
+						RT_SECTION(7);
+						if (ph == PH_SHADE)
+							do_shade(std::integral_constant<int, 2>{});
+						RT_SECTION(8);
 	#endif
+					}
 				}
 	#if RT_PQ_SPLIT
 				if (METHOD == 1) {
