@@ -1250,6 +1250,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				// kernels: config 2 28.46 -> 28.02 ms at 256 spp, same box, three rounds.  The simple / full variants keep one region
 				// per step: fused, config 3 measured 42.3 -> 43.3 ms (their spilled registers move into the longer region).
 				constexpr bool kFuseRegions = METHOD == 1 && RT_PQ_SPLIT && KernelShape<F>::spheres_only;
+				bool run_q = run_light;
 				if (!run_light) {
 					if (kFuseRegions) {
 						if (ph == PH_GEN) {
@@ -1260,6 +1261,15 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 							do_shade(std::integral_constant<int, 1>{});
 						}
 						RT_SECTION(3);
+						// enough paths wait for BOUNCE now?  Then run it in this iteration: the same sequence of phases the vote at the
+						// top of the next iteration would choose, without the trip round the loop in between
+						const uint32_t n_light_now = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
+						run_q = n_light_now >= kLightPhaseThreshold;
+	#ifdef RT_STATS
+						if (run_q && lane == 0u) {
+							st_iters[1] += 1; st_active[1] += n_light_now;
+						}
+	#endif
 					} else {
 						if (ph == PH_GEN)
 							do_gen();
@@ -1270,7 +1280,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 							do_shade(std::integral_constant<int, (METHOD == 1 && RT_PQ_SPLIT) ? 1 : 0>{});
 						RT_SECTION(3);
 					}
-				} else {
+				}
+				if (run_q) {
 					LightCtx L; // loop-local: see LightCtx above
 					L.l_wi = v3s(0.0f);
 					L.pdf_multiplier = 1.0f;

@@ -28,7 +28,7 @@ template <int KIND> __global__ __launch_bounds__(256) void loop_kernel(unsigned 
 		if (KIND == 8) { REP64(asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0\n v_div_fixup_f32 %2, %2, %1, %3\n v_div_fmas_f32 %3, %3, %1, %2\n v_alignbit_b32 %4, %4, %4, 7" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd), "+v"(a) : : "vcc");) }
 		if (KIND == 9) { REP64(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));) }
 		if (KIND == 10) { REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_mov_b32 %1, %2\n v_cndmask_b32 %2, %2, %3, vcc\n v_mov_b32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : );) }
-		if (KIND == 11) { REP64(asm volatile("s_and_b64 vcc, vcc, exec\n s_or_b64 vcc, vcc, exec\n s_mov_b32 m0, 0\n s_add_u32 m0, m0, 1" : : : "vcc", "m0");) }
+		if (KIND == 11) { REP64(asm volatile("s_and_b64 vcc, vcc, exec\n s_or_b64 vcc, vcc, exec\n s_mov_b32 vcc_lo, 0\n s_add_u32 vcc_lo, vcc_lo, 1"   : : : "vcc");) }
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ __float_as_uint(fa + fb + fc + fd) ^ (unsigned)(qa ^ qb);
 }
@@ -38,14 +38,16 @@ template <int KIND> static double run(const char *name, int waves_per_simd, unsi
 	const int n_cu = 256, blocks = n_cu * waves_per_simd; // 256 threads = 4 waves = one per SIMD
 	const unsigned n_iter = 200;
 	hipEvent_t e0, e1;
-	hipEventCreate(&e0); hipEventCreate(&e1);
+	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 	hipLaunchKernelGGL(loop_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10u, 1u);
-	hipEventRecord(e0);
+	(void)hipEventRecord(e0);
 	hipLaunchKernelGGL(loop_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, n_iter, 3u);
-	hipEventRecord(e1);
-	hipEventSynchronize(e1);
+	(void)hipEventRecord(e1);
+	const hipError_t se = hipEventSynchronize(e1);
 	float ms = 0;
-	hipEventElapsedTime(&ms, e0, e1);
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	if (se != hipSuccess || hipGetLastError() != hipSuccess)
+		std::printf("%-34s waves/SIMD %d: HIP error %s\n", name, waves_per_simd, hipGetErrorString(se));
 	const double instr_per_wave = (double)n_iter * 64 * 4;
 	const double cycles = ms * 1e-3 * clock_ghz * 1e9;
 	const double per_simd = cycles / (instr_per_wave * waves_per_simd); // cycles of SIMD time per wave-instruction
@@ -55,9 +57,10 @@ template <int KIND> static double run(const char *name, int waves_per_simd, unsi
 
 int main(int argc, char **argv)
 {
+	setvbuf(stdout, nullptr, _IONBF, 0);
 	const double clock_ghz = 2.4;
 	unsigned *d_out = nullptr;
-	hipMalloc(&d_out, 256 * 8 * 256 * sizeof(unsigned));
+	if (hipMalloc(&d_out, 256 * 8 * 256 * sizeof(unsigned)) != hipSuccess) { std::printf("hipMalloc failed\n"); return 1; }
 	for (int w : {1, 2, 4}) {
 		run<0>("v_fma_f32", w, d_out, clock_ghz);
 		run<5>("v_xor_b32", w, d_out, clock_ghz);
@@ -72,6 +75,6 @@ int main(int argc, char **argv)
 		run<8>("v_div_scale/fixup/fmas/alignbit mix", w, d_out, clock_ghz);
 		run<11>("SALU (s_and/s_or/s_mov/s_add)", w, d_out, clock_ghz);
 	}
-	hipFree(d_out);
+	(void)hipFree(d_out);
 	return 0;
 }
