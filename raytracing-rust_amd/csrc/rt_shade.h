@@ -195,6 +195,17 @@ template <class F> __device__ __forceinline__ V3 material_texture_colour(const D
 	return texture_colour<F>(S, m.texture, direction, point);
 }
 
+// A wave-uniform value the optimiser must not see through: conversions and products of it are then computed where they are used
+// (one or two instructions) instead of being hoisted out of the persistent loop into a VGPR that lives -- or is spilled to
+// scratch and reloaded on the hot path -- for the whole kernel.
+__device__ __forceinline__ uint32_t here_(uint32_t uniform)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+s"(uniform));
+#endif
+	return uniform;
+}
+
 // ---- statistics/distributions.rs ----
 // Distribution1D::sample :51-72 over a cdf of n+1 entries
 // `guide` (may be null; wave-uniform): guide_k upper-bound indices for this cdf, see DevSky in rt_types.h
@@ -205,8 +216,18 @@ __device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, 
 	if (guide != nullptr) {
 		// the upper bound of num lies at or right of the upper bound of floor(num * K) / K
 		first = guide[(uint32_t)(num * (float)guide_k)];
-		while (first <= n && cdf[first] <= num)
-			++first;
+		// `while (first <= n && cdf[first] <= num) ++first;` -- two entries per round of reads instead of one: the CDF is
+		// non-decreasing (the guide tables are built only then), so the entries that are <= num form a prefix and the scan may
+		// look ahead; one round of two INDEPENDENT reads usually ends it (four at a time cost the config-2 kernel 14 spilled registers), where the one-at-a-time loop paid a dependent
+		// LDS round trip per step
+		for (;;) {
+			const float c0 = cdf[first > n ? n : first], c1 = cdf[first + 1u > n ? n : first + 1u];
+			const bool b0 = first <= n && c0 <= num;
+			const bool b1 = b0 && first + 1u <= n && c1 <= num;
+			first += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
+			if (!b1)
+				break;
+		}
 	} else {
 		first = 0;
 		uint32_t len = n + 1;
@@ -247,7 +268,7 @@ __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, 
 		phi += 2.0f * kPi;
 	const float u = phi / (2.0f * kPi);
 	const float v = div_tame_fix_(theta, kPi); // acos returns zero, NaN or at least 2 asin(2^-12.5) = 3.4e-4
-	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
+	const uint32_t rx = here_(S.sky.res_x), ry = here_(S.sky.res_y);
 	uint32_t ui = f32_as_index((float)rx * u);
 	uint32_t vi = f32_as_index((float)ry * v);
 	ui = ui > rx - 1u ? rx - 1u : ui;
@@ -262,7 +283,7 @@ __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, 
 // Sky::sample  sky.rs:64-78
 __device__ __forceinline__ V3 sky_sample(const DevScene &S, const SkyTables &T, rt_rng &rng)
 {
-	const uint32_t rx = S.sky.res_x, ry = S.sky.res_y;
+	const uint32_t rx = here_(S.sky.res_x), ry = here_(S.sky.res_y);
 	const bool guided = T.guide_k != 0u;
 	const uint32_t sv = dist1d_sample(T.marginal_cdf, ry, guided ? T.guide + (size_t)ry * T.guide_k : nullptr, T.guide_k, rng);
 	const uint32_t su = dist1d_sample(T.row_cdf + (size_t)sv * (rx + 1u), rx, guided ? T.guide + (size_t)sv * T.guide_k : nullptr, T.guide_k, rng);

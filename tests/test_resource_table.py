@@ -45,10 +45,12 @@ def test_default_kernels_match_the_committed_table(built_table):
 
 def test_headline_kernels_hold_their_budgets(built_table):
     """the kernels of BASELINE configs 2 and 3 (coarse schedule, MIS, sky tables in LDS): 4 waves per SIMD and, since the
-    kernel arguments are read where they are used (RenderArgs in rt_render.hip), no SGPR spills to speak of and no scratch
-    in the spheres-only kernel"""
+    kernel arguments are read where they are used (RenderArgs in rt_render.hip), no SGPR spills to speak of and next to no
+    scratch in the spheres-only kernel"""
     spheres = built_table["void rt::render_kernel<1, false, false, true, rt::Feat<false, false, false, false>, false>"]
     simple = built_table["void rt::render_kernel<1, false, false, true, rt::Feat<true, true, false, false>, false>"]
     assert spheres["waves_per_simd_by_registers"] >= 4 and simple["waves_per_simd_by_registers"] >= 4
-    assert spheres["private_segment_fixed_size"] == 0 and spheres["vgpr_spill_count"] == 0
+    # (running BOUNCE in the iteration whose PRIMARY filled it parks 13 loop-invariant / rarely used registers in 40 bytes of
+    # scratch and is still 1 % faster than the spill-free loop, same-box A/B gpurun_out/r03r: that much is allowed, no more)
+    assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 14
     assert spheres["sgpr_spill_count"] <= 24
