@@ -562,14 +562,79 @@ __device__ __forceinline__ bool root_box_misses(const DevScene &S, const Ray &r)
 	return !aabb_does_int(S.root_min, S.root_max, r, tm);
 }
 
+// ---- wave-uniform loads, for the walk of a two-leaf tree (below): the node and the primitives of its leaves are the same
+// for every lane, so ONE scalar load brings a record into SGPRs for the whole wave.  The compiler emits scalar loads by
+// itself only through `const __restrict__` kernel arguments (a pointer that was itself loaded from memory might alias
+// the frame), and three more kernel arguments cost the fine kernels 10 % (rt_render.hip); hence the instruction is written
+// out.  `p` must be wave-uniform and point at global memory nothing writes during the kernel. ----
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// (the pointer IS wave-uniform; where the compiler's divergence analysis cannot tell, this puts it into SGPRs -- and folds away where it can)
+template <class T> __device__ __forceinline__ const T *as_scalar_pointer(const T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint64_t a = reinterpret_cast<uint64_t>(p);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+	return reinterpret_cast<const T *>(((uint64_t)hi << 32) | lo);
+#else
+	return p;
+#endif
+}
+__device__ __forceinline__ NodeView load_node_uniform(const DevNode *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	p = as_scalar_pointer(p);
+	u32x16_t q;
+	asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q) : "s"(p) : "memory");
+	NodeView n;
+	n.c0min[0] = __uint_as_float(q[0]); n.c0min[1] = __uint_as_float(q[1]); n.c0min[2] = __uint_as_float(q[2]);
+	n.c0max[0] = __uint_as_float(q[3]); n.c0max[1] = __uint_as_float(q[4]); n.c0max[2] = __uint_as_float(q[5]);
+	n.c1min[0] = __uint_as_float(q[6]); n.c1min[1] = __uint_as_float(q[7]); n.c1min[2] = __uint_as_float(q[8]);
+	n.c1max[0] = __uint_as_float(q[9]); n.c1max[1] = __uint_as_float(q[10]); n.c1max[2] = __uint_as_float(q[11]);
+	n.c0 = q[12];
+	n.c1 = q[13];
+	return n;
+#else
+	NodeView n{};
+	(void)p;
+	return n;
+#endif
+}
+template <class F> __device__ __forceinline__ PrimGeom load_prim_uniform(const DevPrim *p)
+{
+	PrimGeom g;
+#if defined(__HIP_DEVICE_COMPILE__)
+	p = as_scalar_pointer(p);
+	u32x8_t ab;
+	asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ab) : "s"(p) : "memory");
+	const uint32_t meta = ab[3];
+	g.type = meta & 3u;
+	g.material = meta >> 2;
+	g.p0 = v3(__uint_as_float(ab[0]), __uint_as_float(ab[1]), __uint_as_float(ab[2]));
+	g.p1 = v3(__uint_as_float(ab[4]), __uint_as_float(ab[5]), __uint_as_float(ab[6]));
+	g.p2 = v3(0.0f, 0.0f, 0.0f);
+	if (F::tri && g.type != kPrimSphere) { // (wave-uniform branch)
+		u32x4_t c;
+		asm volatile("s_load_dwordx4 %0, %1, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(p) : "memory");
+		g.p2 = v3(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2]));
+	}
+#else
+	(void)p;
+	g.type = g.material = 0u;
+	g.p0 = g.p1 = g.p2 = v3(0.0f, 0.0f, 0.0f);
+#endif
+	return g;
+}
+
 // the primitive loop of Bvh::check_hit for one leaf: selection rule of mod.rs:270-293
-template <class F>
+template <class F, bool UNIFORM = false>
 __device__ __forceinline__ void closest_in_leaf(const DevScene &S, const Ray &r, uint32_t leaf, float &best_t, uint32_t &best_prim)
 {
 	uint32_t first, count;
 	leaf_range(S, leaf, first, count);
 	for (uint32_t slot = first; slot < first + count; ++slot) {
-		const PrimGeom g = load_prim<F>(S, slot);
+		const PrimGeom g = UNIFORM ? load_prim_uniform<F>(&S.prims[slot]) : load_prim<F>(S, slot);
 		float t;
 		if (prim_t<F>(g, r, t) && t > 0.0f) {
 			bool take;
@@ -589,7 +654,7 @@ __device__ __forceinline__ void closest_in_leaf(const DevScene &S, const Ray &r,
 	}
 }
 // ... and of the occlusion rule (see trace_any)
-template <class F>
+template <class F, bool UNIFORM = false>
 __device__ __forceinline__ bool any_in_leaf(const DevScene &S, const Ray &r, uint32_t leaf, float t_limit, uint32_t skip)
 {
 	uint32_t first, count;
@@ -597,7 +662,7 @@ __device__ __forceinline__ bool any_in_leaf(const DevScene &S, const Ray &r, uin
 	for (uint32_t slot = first; slot < first + count; ++slot) {
 		if (slot == skip)
 			continue;
-		const PrimGeom g = load_prim<F>(S, slot);
+		const PrimGeom g = UNIFORM ? load_prim_uniform<F>(&S.prims[slot]) : load_prim<F>(S, slot);
 		float t;
 		if (prim_t<F>(g, r, t) && t > 0.0f && !(t >= t_limit))
 			return true;
@@ -620,14 +685,14 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 	if (!PRUNE && is_two_leaf_tree(S)) {
 		// SU is the scene as the kernel received it (global memory): every address below is wave-uniform,
 		// so the node and the primitives arrive through scalar loads and the tests read them from SGPRs
-		const NodeView n = load_node(SU, 0u);
+		const NodeView n = load_node_uniform(SU.nodes);
 		float t0, t1;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
 #pragma unroll 1
 		for (int c = 0; c < 2; ++c)
 			if (c == 0 ? h0 : h1)
-				closest_in_leaf<F>(SU, r, c == 0 ? n.c0 : n.c1, best_t, best_prim);
+				closest_in_leaf<F, true>(SU, r, c == 0 ? n.c0 : n.c1, best_t, best_prim);
 		return;
 	}
 	int sp = 0;
@@ -661,7 +726,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 		return false;
 	const bool limited = !(t_limit != t_limit);
 	if (!PRUNE && is_two_leaf_tree(S)) {
-		const NodeView n = load_node(SU, 0u);
+		const NodeView n = load_node_uniform(SU.nodes);
 		float t0, t1;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
@@ -669,7 +734,7 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 #pragma unroll 1
 		for (int c = 0; c < 2; ++c)
 			if (!occluded && (c == 0 ? h0 : h1))
-				occluded = any_in_leaf<F>(SU, r, c == 0 ? n.c0 : n.c1, t_limit, skip);
+				occluded = any_in_leaf<F, true>(SU, r, c == 0 ? n.c0 : n.c1, t_limit, skip);
 		return occluded;
 	}
 	int sp = 0;

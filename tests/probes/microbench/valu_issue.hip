@@ -17,7 +17,7 @@ template <int KIND> __global__ __launch_bounds__(256) void loop_kernel(unsigned 
 	unsigned long long qa = a, qb = b;
 	for (unsigned i = 0; i < n_iter; ++i) {
 		// four independent chains, 64 instructions of the kind per chain per iteration
-		if (KIND == 0) { REP64(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %4, %4, %1, %2\n v_fma_f32 %5, %5, %1, %2" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd), "+v"(fa), "+v"(fb) : : );) }
+		if (KIND == 0) { REP64(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd) : "v"(0.999f), "v"(1.0e-3f));) }
 		if (KIND == 1) { REP64(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed | 1u));) }
 		if (KIND == 2) { REP64(asm volatile("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed | 0xF0000001u));) }
 		if (KIND == 3) { REP64(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1" : "+v"(qa), "+v"(qb) : "v"(a), "v"(seed | 1u) : "vcc");) }
@@ -28,7 +28,6 @@ template <int KIND> __global__ __launch_bounds__(256) void loop_kernel(unsigned 
 		if (KIND == 8) { REP64(asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0\n v_div_fixup_f32 %2, %2, %1, %3\n v_div_fmas_f32 %3, %3, %1, %2\n v_alignbit_b32 %4, %4, %4, 7" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd), "+v"(a) : : "vcc");) }
 		if (KIND == 9) { REP64(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));) }
 		if (KIND == 10) { REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_mov_b32 %1, %2\n v_cndmask_b32 %2, %2, %3, vcc\n v_mov_b32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : );) }
-		if (KIND == 11) { REP64(asm volatile("s_and_b64 vcc, vcc, exec\n s_or_b64 vcc, vcc, exec\n s_mov_b32 vcc_lo, 0\n s_add_u32 vcc_lo, vcc_lo, 1"   : : : "vcc");) }
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ __float_as_uint(fa + fb + fc + fd) ^ (unsigned)(qa ^ qb);
 }
@@ -36,7 +35,7 @@ template <int KIND> __global__ __launch_bounds__(256) void loop_kernel(unsigned 
 template <int KIND> static double run(const char *name, int waves_per_simd, unsigned *d_out, double clock_ghz)
 {
 	const int n_cu = 256, blocks = n_cu * waves_per_simd; // 256 threads = 4 waves = one per SIMD
-	const unsigned n_iter = 200;
+	const unsigned n_iter = 2000;
 	hipEvent_t e0, e1;
 	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 	hipLaunchKernelGGL(loop_kernel<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10u, 1u);
@@ -73,7 +72,6 @@ int main(int argc, char **argv)
 		run<4>("v_rcp_f32", w, d_out, clock_ghz);
 		run<9>("v_sqrt_f32", w, d_out, clock_ghz);
 		run<8>("v_div_scale/fixup/fmas/alignbit mix", w, d_out, clock_ghz);
-		run<11>("SALU (s_and/s_or/s_mov/s_add)", w, d_out, clock_ghz);
 	}
 	(void)hipFree(d_out);
 	return 0;
