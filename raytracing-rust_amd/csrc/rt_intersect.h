@@ -627,6 +627,56 @@ template <class F> __device__ __forceinline__ PrimGeom load_prim_uniform(const D
 	return g;
 }
 
+// ... two records in ONE round of scalar loads (a two-leaf tree whose leaves hold one primitive each: rtweekend1).  Measured
+// same-box: 27.4 -> 25.5 ms on config 2 at 256 spp.  Fetching the node in that same round as well (slots supplied by the host)
+// was measured too: no further gain, three more VGPR spills; so was handing the winner's record (selected from these registers)
+// on to make_hit instead of its own fetch: 25.9 -> 27.1 ms, twenty more spilled VGPRs.
+template <class F> __device__ __forceinline__ void load_prim_pair_uniform(const DevPrim *pa, const DevPrim *pb, PrimGeom &ga, PrimGeom &gb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	pa = as_scalar_pointer(pa);
+	pb = as_scalar_pointer(pb);
+	u32x8_t a, b;
+	u32x4_t ca = {0u, 0u, 0u, 0u}, cb = {0u, 0u, 0u, 0u};
+	if (F::tri)
+		asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %5, 0x0\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %5, 0x20\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&s"(a), "=&s"(b), "=&s"(ca), "=&s"(cb) : "s"(pa), "s"(pb) : "memory");
+	else
+		asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(pa), "s"(pb) : "memory");
+	auto unpack = [](const u32x8_t &q, const u32x4_t &c, PrimGeom &g) {
+		g.type = q[3] & 3u;
+		g.material = q[3] >> 2;
+		g.p0 = v3(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]));
+		g.p1 = v3(__uint_as_float(q[4]), __uint_as_float(q[5]), __uint_as_float(q[6]));
+		g.p2 = (F::tri && g.type != kPrimSphere) ? v3(__uint_as_float(c[0]), __uint_as_float(c[1]), __uint_as_float(c[2])) : v3(0.0f, 0.0f, 0.0f);
+	};
+	unpack(a, ca, ga);
+	unpack(b, cb, gb);
+#else
+	(void)pa; (void)pb;
+	ga.type = ga.material = gb.type = gb.material = 0u;
+	ga.p0 = ga.p1 = ga.p2 = gb.p0 = gb.p1 = gb.p2 = v3(0.0f, 0.0f, 0.0f);
+#endif
+}
+// the selection rule of Bvh::check_hit (mod.rs:270-293) for one candidate: smallest t > 0, ties to the first in BFS-leaf order
+__device__ __forceinline__ bool leaf_holds_one(uint32_t ref) { return ((ref >> 26) & 31u) == 1u; }
+__device__ __forceinline__ void consider_closest(const DevScene &S, uint32_t slot, float t, float &best_t, uint32_t &best_prim)
+{
+	bool take;
+	if (best_prim == kNoPrim)
+		take = true;
+	else if (t < best_t)
+		take = true;
+	else if (t == best_t)
+		take = S.prim_rank[slot] < S.prim_rank[best_prim];
+	else
+		take = false;
+	if (take) {
+		best_t = t;
+		best_prim = slot;
+	}
+}
+
 // the primitive loop of Bvh::check_hit for one leaf: selection rule of mod.rs:270-293
 template <class F, bool UNIFORM = false>
 __device__ __forceinline__ void closest_in_leaf(const DevScene &S, const Ray &r, uint32_t leaf, float &best_t, uint32_t &best_prim)
@@ -689,6 +739,17 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 		float t0, t1;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		if (leaf_holds_one(n.c0) && leaf_holds_one(n.c1)) { // (wave-uniform) one primitive per leaf: both records in one round of loads
+			const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
+			PrimGeom g0, g1;
+			load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
+			float t;
+			if (h0 && prim_t<F>(g0, r, t) && t > 0.0f)
+				consider_closest(SU, s0, t, best_t, best_prim);
+			if (h1 && prim_t<F>(g1, r, t) && t > 0.0f)
+				consider_closest(SU, s1, t, best_t, best_prim);
+			return;
+		}
 #pragma unroll 1
 		for (int c = 0; c < 2; ++c)
 			if (c == 0 ? h0 : h1)
@@ -730,6 +791,15 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 		float t0, t1;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		if (leaf_holds_one(n.c0) && leaf_holds_one(n.c1)) { // (wave-uniform) as in trace_closest
+			const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
+			PrimGeom g0, g1;
+			load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
+			float t;
+			if (h0 && s0 != skip && prim_t<F>(g0, r, t) && t > 0.0f && !(t >= t_limit))
+				return true;
+			return h1 && s1 != skip && prim_t<F>(g1, r, t) && t > 0.0f && !(t >= t_limit);
+		}
 		bool occluded = false;
 #pragma unroll 1
 		for (int c = 0; c < 2; ++c)
