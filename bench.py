@@ -485,7 +485,10 @@ def main():
                          "note": "achieved = bytes the pruned walk REQUESTS (48 B/node step + 48 B/primitive test, counted live) / kernel time; "
                                  "fabric_GBps_from_pmc = what crossed the fabric (Infinity Cache + HBM, 128-byte lines) in the committed profile "
                                  "of this build: above the requested bytes because a node step uses 48 bytes of the 128-byte line it arrives in "
-                                 "(the line count, not the byte count, is what HBM serves: fabric_frac_of_achievable is the saturation figure)"})
+                                 "(the line count, not the byte count, is what HBM serves).  fabric_frac_of_achievable is NOT the binding limit, "
+                                 "though it reads like one: eight-child nodes moved 22 % fewer lines over the fabric and the launch got 6 % slower "
+                                 "(profiles/r04w8_mesh10m_pmc.json against r03n; DESIGN.md section 5 (5)): the launch follows lane-level 16-byte "
+                                 "fetches and VALU instructions, HBM is the nearest roofline"})
         ab = w["bytes"]
         ap = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")  # the oracle's own count, when it has been made for this workload
         if os.path.exists(ap):
