@@ -296,7 +296,10 @@ int rt_scene_set_traversal(rt_scene *scene, int mode);
  *   RT_TUNE_TRAVERSAL     as rt_scene_set_traversal
  *   RT_TUNE_FEATURE_SET   0 spheres-only, 1 + triangles and emissive primitives, 2 every material /
  *                         texture; the library picks the smallest that covers the scene, a caller may
- *                         only raise it
+ *                         only raise it.  A scene whose tree is ONE node over two leaves of one sphere each
+ *                         (rtweekend1.ssml) runs, where set 0 would run under the exhaustive coarse schedule,
+ *                         kernels compiled for exactly that tree (rt_launch_info.feature_set = 3); naming a
+ *                         set here, 0 included, turns that off (same pixels: a test renders both)
  *   RT_TUNE_SCENE_IN_LDS  1 (default): tiny scenes are staged whole into LDS; 0: read from HBM/L2
  *   RT_TUNE_SCHEDULE      -1 automatic, 0 coarse (two voted super-phases), 1 fine (every step of the
  *                         per-lane state machine is voted; implies the pruned walk)
@@ -369,7 +372,7 @@ typedef struct rt_launch_info {
 	int32_t fine;           /* 1: every phase voted (big trees), 0: two super-phases */
 	int32_t sky_in_lds;     /* sky CDF + guide tables staged in LDS */
 	int32_t scene_in_lds;   /* whole scene staged in LDS (tiny scenes) */
-	int32_t feature_set;    /* 0 spheres-only, 1 simple, 2 full */
+	int32_t feature_set;    /* 0 spheres-only, 1 simple, 2 full, 3 spheres-only specialised for a two-leaf tree */
 	uint32_t block_threads; /* workgroup size */
 	uint32_t n_blocks;      /* persistent grid */
 	uint32_t blocks_per_cu; /* resident workgroups per CU (occupancy query) */

@@ -94,6 +94,9 @@ struct rt_scene {
 	int schedule_mode = -1;  // -1 auto, 0 coarse (two super-phases), 1 fine (every step voted)
 	int feature_set = 2;     // smallest kernel variant covering the scene: 0 spheres-only, 1 simple, 2 full
 	int min_feature_set = 0; // what the scene needs (feature_set may be forced larger for tests)
+	// the tree is one inner node over two leaves of one primitive each: launches that would run the spheres-only exhaustive
+	// coarse kernels run their FeatPair twins (rt_types.h) -- unless a feature set was asked for by name (RT_TUNE_FEATURE_SET)
+	bool pair_tree = false, feature_set_forced = false;
 	bool scene_lds_allowed = true;
 	float *d_partial = nullptr; // sample_split > 1: per-chunk means, grown on demand
 	size_t partial_floats = 0;
@@ -338,6 +341,10 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 		else
 			s->feature_set = 0;
 		s->min_feature_set = s->feature_set;
+		if (h.dev_nodes.size() == 1 && (h.root_ref & kLeafFlag) == 0u) {
+			const DevNode &n0 = h.dev_nodes[0];
+			s->pair_tree = (n0.c0 & kLeafFlag) && (n0.c1 & kLeafFlag) && ((n0.c0 >> 26) & 31u) == 1u && ((n0.c1 >> 26) & 31u) == 1u;
+		}
 	}
 	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
 		if (std::strcmp(e, "exhaustive") == 0) s->traversal_mode = 0;
@@ -544,6 +551,7 @@ static int set_tuning_one(rt_scene *s, int key, int value)
 		if (value < s->min_feature_set || value > 2)
 			return fail(RT_ERR_INVALID_ARGUMENT, "feature set must be between the scene's own and 2");
 		s->feature_set = value;
+		s->feature_set_forced = true;
 		return RT_OK;
 	case RT_TUNE_SCHEDULE:
 		if (value < -1 || value > 1)
@@ -1005,9 +1013,12 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	bool sky_lds = false;
 	// RT_TUNE_EXCHANGE (rt_render.hip, XCHG).  Fine schedule: 512-thread workgroups whose waves trade whole lane states
 	// through two record pools behind the stacks; coarse MIS kernels: decided below, once the occupancy is known
-	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, s->feature_set);
+	// (feature set of THIS launch: 3 = FeatPair, built for the exhaustive coarse kernels without the exchange only)
+	const int feature_set =
+	    (s->feature_set == 0 && s->pair_tree && !s->feature_set_forced && !prune && !fine && s->exchange_mode != 1) ? 3 : s->feature_set;
+	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, feature_set);
 	const bool xchg_fine = xchg && fine;
-	const uint32_t block_threads = render_block_threads(s->feature_set, fine, xchg_fine);
+	const uint32_t block_threads = render_block_threads(feature_set, fine, xchg_fine);
 	const size_t fine_pool_bytes = xchg_fine ? render_exchange_fine_lds_bytes(block_threads / 64u) : 0;
 	// Traversal stacks: one LDS column per lane.  The worst case of a deep tree (three pending siblings per level of
 	// the wide tree) is far above what walks reach, and LDS sized for it would cost resident waves; under the fine
@@ -1021,13 +1032,13 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	const bool walks_wide = prune && dev.nodes4 != nullptr && dev.narrow_only == 0u;
 	uint32_t stack_need = (fine || walks_wide) ? dev.stack_depth : s->stack_depth_narrow;
 	if (!fine && walks_wide &&
-	    render_lds_bytes(dev, false, scene_lds, render_block_threads(s->feature_set, false, false) / 64u, stack_need) > s->max_lds) {
+	    render_lds_bytes(dev, false, scene_lds, render_block_threads(feature_set, false, false) / 64u, stack_need) > s->max_lds) {
 		dev.narrow_only = 1u;
 		stack_need = s->stack_depth_narrow;
 	}
 	uint32_t stack_cap = stack_need;
 	if (fine) {
-		const uint32_t blocks_wanted = std::max(1u, render_waves_per_simd(s->feature_set, true) * 256u / block_threads);
+		const uint32_t blocks_wanted = std::max(1u, render_waves_per_simd(feature_set, true) * 256u / block_threads);
 		const size_t share = s->max_lds / blocks_wanted;
 		const uint32_t fit = (uint32_t)((share > fine_pool_bytes ? share - fine_pool_bytes : 0) / ((block_threads / 64u) * 64u * 4u));
 		stack_cap = std::min(stack_cap, std::max(8u, fit));
@@ -1040,12 +1051,12 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	if (lds_bytes > s->max_lds)
 		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
 	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, s->feature_set, lds_bytes, &blocks_per_cu, xchg_fine));
+	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, feature_set, lds_bytes, &blocks_per_cu, xchg_fine));
 	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
 		const size_t lds_with = render_lds_bytes(dev, true, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
 		int blocks_with = 0;
 		if (lds_with <= s->max_lds &&
-		    render_occupancy(o->render_method, prune, fine, true, s->feature_set, lds_with, &blocks_with, xchg_fine) == hipSuccess &&
+		    render_occupancy(o->render_method, prune, fine, true, feature_set, lds_with, &blocks_with, xchg_fine) == hipSuccess &&
 		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
 			sky_lds = true;
 			lds_bytes = lds_with;
@@ -1065,7 +1076,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 			slots -= 4u;
 		int blocks_x = 0;
 		if (slots >= 16u &&
-		    render_occupancy(o->render_method, prune, fine, sky_lds, s->feature_set, lds_bytes + render_exchange_lds_bytes(slots), &blocks_x, true) == hipSuccess &&
+		    render_occupancy(o->render_method, prune, fine, sky_lds, feature_set, lds_bytes + render_exchange_lds_bytes(slots), &blocks_x, true) == hipSuccess &&
 		    blocks_x >= blocks_per_cu) {
 			P.xchg_slots = slots;
 			lds_bytes += render_exchange_lds_bytes(slots);
@@ -1101,7 +1112,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		L.fine = fine ? 1 : 0;
 		L.sky_in_lds = sky_lds ? 1 : 0;
 		L.scene_in_lds = scene_lds ? 1 : 0;
-		L.feature_set = s->feature_set;
+		L.feature_set = feature_set;
 		L.block_threads = block_threads;
 		L.n_blocks = (uint32_t)n_blocks;
 		L.blocks_per_cu = (uint32_t)blocks_per_cu;
@@ -1110,11 +1121,11 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		L.n_cus = (uint32_t)s->n_cus;
 		L.sample_split = split;
 		L.n_items = P.n_items;
-		static const char *const feat_names[3] = {"rt::Feat<false, false, false, false>", "rt::Feat<true, true, false, false>",
-		                                          "rt::Feat<true, true, true, true>"};
+		static const char *const feat_names[4] = {"rt::Feat<false, false, false, false>", "rt::Feat<true, true, false, false>",
+		                                          "rt::Feat<true, true, true, true>", "rt::FeatPair"};
 		// pick_render (rt_render.hip) folds these: naive never stages the sky, fine implies pruned
 		std::snprintf(L.kernel, sizeof L.kernel, "rt::render_kernel<%d, %s, %s, %s, %s%s>", (int)o->render_method, prune ? "true" : "false",
-		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[s->feature_set],
+		              fine ? "true" : "false", (sky_lds && o->render_method == RT_METHOD_MIS) ? "true" : "false", feat_names[feature_set],
 		              xchg ? ", true" : ", false"); // the name rocprofv3 prints
 	}
 	if (P.stack_ovf_depth != 0u) { // grown on first use only (like the sample_split scratch: not capturable on that call)
@@ -1129,7 +1140,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		}
 	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
-	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, s->feature_set, (uint32_t)n_blocks, lds_bytes, stream, dev, cam, P, render_target,
+	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, feature_set, (uint32_t)n_blocks, lds_bytes, stream, dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)

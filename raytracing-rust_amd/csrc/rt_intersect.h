@@ -732,6 +732,20 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 	best_prim = kNoPrim;
 	if (root_box_misses(S, r))
 		return;
+	if constexpr (F::pair) { // the host launches this set only for such a tree: nothing else is compiled in
+		const NodeView n = load_node_uniform(SU.nodes);
+		float t0, t1, t;
+		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
+		PrimGeom g0, g1;
+		load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
+		if (h0 && prim_t<F>(g0, r, t) && t > 0.0f)
+			consider_closest(SU, s0, t, best_t, best_prim);
+		if (h1 && prim_t<F>(g1, r, t) && t > 0.0f)
+			consider_closest(SU, s1, t, best_t, best_prim);
+		return;
+	}
 	if (!PRUNE && is_two_leaf_tree(S)) {
 		// SU is the scene as the kernel received it (global memory): every address below is wave-uniform,
 		// so the node and the primitives arrive through scalar loads and the tests read them from SGPRs
@@ -786,6 +800,18 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 	if (root_box_misses(S, r))
 		return false;
 	const bool limited = !(t_limit != t_limit);
+	if constexpr (F::pair) { // as in trace_closest
+		const NodeView n = load_node_uniform(SU.nodes);
+		float t0, t1, t;
+		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
+		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
+		const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
+		PrimGeom g0, g1;
+		load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
+		if (h0 && s0 != skip && prim_t<F>(g0, r, t) && t > 0.0f && !(t >= t_limit))
+			return true;
+		return h1 && s1 != skip && prim_t<F>(g1, r, t) && t > 0.0f && !(t >= t_limit);
+	}
 	if (!PRUNE && is_two_leaf_tree(S)) {
 		const NodeView n = load_node_uniform(SU.nodes);
 		float t0, t1;

@@ -1847,7 +1847,7 @@ uint32_t render_block_threads(int feature_set, bool fine, bool xchg)
 {
 	if (fine && xchg)
 		return 512u; // KernelShape<F, true, true>::block
-	if (feature_set == 0)
+	if (feature_set == 0 || feature_set == 3)
 		return (uint32_t)KernelShape<Feat<false, false, false, false>>::block;
 	if (feature_set == 1)
 		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::block : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::block;
@@ -1857,7 +1857,7 @@ uint32_t render_block_threads(int feature_set, bool fine, bool xchg)
 // waves per SIMD the kernel's register budget is declared for (its __launch_bounds__)
 uint32_t render_waves_per_simd(int feature_set, bool fine)
 {
-	if (feature_set == 0)
+	if (feature_set == 0 || feature_set == 3)
 		return fine ? (uint32_t)KernelShape<Feat<false, false, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<false, false, false, false>, false>::waves_per_simd;
 	if (feature_set == 1)
 		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::waves_per_simd;
@@ -1890,6 +1890,13 @@ template <class F> static render_fn pick_render_f(int method, bool prune, bool f
 			return render_kernel<1, false, false, true, F>;
 	return nullptr;
 #else
+	if constexpr (F::pair) { // the exhaustive coarse kernels only: that is where the host uses this set (rt_api.cpp)
+		if (xchg || prune || fine)
+			return nullptr;
+		if (method == 0)
+			return render_kernel<0, false, false, false, F>;
+		return sky_lds ? render_kernel<1, false, false, true, F> : render_kernel<1, false, false, false, F>;
+	} else {
 	if (xchg) { // built for the coarse exhaustive MIS kernels (configs 2 and 3) and for the fine schedule
 		if (method == 1 && !prune && !fine)
 			return sky_lds ? render_kernel<1, false, false, true, F, true> : render_kernel<1, false, false, false, F, true>;
@@ -1914,10 +1921,11 @@ template <class F> static render_fn pick_render_f(int method, bool prune, bool f
 	RT_PICK(1, true, true, true)
 #undef RT_PICK
 	return nullptr;
+	}
 #endif
 }
 
-// feature_set: 0 spheres-only, 1 simple, 2 full
+// feature_set: 0 spheres-only, 1 simple, 2 full, 3 spheres-only over a two-leaf tree of single primitives (FeatPair)
 static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, bool xchg = false)
 {
 	if (method == 0)
@@ -1928,6 +1936,8 @@ static render_fn pick_render(int method, bool prune, bool fine, bool sky_lds, in
 		return pick_render_f<FeatSpheres>(method, prune, fine, sky_lds, xchg);
 	if (feature_set == 1)
 		return pick_render_f<FeatSimple>(method, prune, fine, sky_lds, xchg);
+	if (feature_set == 3)
+		return pick_render_f<FeatPair>(method, prune, fine, sky_lds, xchg);
 	return pick_render_f<FeatFull>(method, prune, fine, sky_lds, xchg);
 }
 bool render_exchange_available(int method, bool prune, bool fine, int feature_set) { (void)feature_set; return fine || (method == 1 && !prune); }

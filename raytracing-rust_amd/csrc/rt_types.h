@@ -30,8 +30,16 @@ template <bool TRI, bool LIGHTS, bool CMAT, bool CTEX> struct Feat {
 	static constexpr bool lights = LIGHTS; // emissive primitives (Bvh.lights non-empty)
 	static constexpr bool cmat = CMAT;     // Reflect / Refract / TrowbridgeReitz materials
 	static constexpr bool ctex = CTEX;     // Checkered / Image / Perlin textures
+	static constexpr bool pair = false;    // (see FeatPair)
 };
 using FeatFull = Feat<true, true, true, true>;
+// The smallest set plus one fact about the TREE: one inner node over two leaves of one primitive each (scenes/rtweekend1.ssml:
+// the ground and one sphere).  The walk is then two box tests and two sphere tests on records that arrive through one
+// round of scalar loads (rt_intersect.h), and with the general walk not even compiled in the coarse kernels need no
+// spilled register (profiles/resource_table.json).  Chosen by the host per launch (rt_api.cpp), like every other set.
+struct FeatPair : Feat<false, false, false, false> {
+	static constexpr bool pair = true;
+};
 
 // child reference: bit 31 clear = inner node index; bit 31 set = leaf, bits 26-30 primitive count
 // (1..31; 0 = entry of DevScene::big_leaves), bits 0-25 first primitive slot (or big-leaf index)

@@ -38,7 +38,7 @@ def test_default_kernels_match_the_committed_table(built_table):
     committed = json.load(open(rtab.TABLE))["kernels"]
     default_built = {k: v for k, v in built_table.items() if v["default"]}
     default_committed = {k: v for k, v in committed.items() if v["default"]}
-    assert len(default_built) >= 27 + 4  # 27 render instantiations the library selects from + the batch-query kernels
+    assert len(default_built) >= 30 + 4  # 30 render instantiations the library selects from + the batch-query kernels
     differences = rtab.diff(default_built, default_committed)
     assert not differences, "\n".join(differences)
 
@@ -54,3 +54,8 @@ def test_headline_kernels_hold_their_budgets(built_table):
     # scratch and is still 1 % faster than the spill-free loop, same-box A/B gpurun_out/r03r: that much is allowed, no more)
     assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 14
     assert spheres["sgpr_spill_count"] <= 24
+    # the kernel BASELINE config 2 itself runs (rtweekend1's tree is one node over two single-sphere leaves: rt_types.h FeatPair,
+    # the general walk not compiled in): no spilled register of either kind, no scratch
+    pair = built_table["void rt::render_kernel<1, false, false, true, rt::FeatPair, false>"]
+    assert pair["waves_per_simd_by_registers"] >= 4
+    assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] == 0
