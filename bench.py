@@ -51,6 +51,7 @@ HBM_ACHIEVABLE_GBS = 6290.0
 CLOCK_HZ = 2.4e9               # max engine clock (MI355X_MICROARCH.md chip-level parameters)
 SIMDS = 256 * 4
 VALU_ISSUE_PEAK = SIMDS * CLOCK_HZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32
+VALU_PLAIN_CYCLES_MEASURED = 2.75  # what a SIMD really spends per plain VALU wave-instruction with 2 or 4 waves on it (profiles/r03_valu_issue.txt)
 # dependent random record fetches, every lane its own chain (tests/microbench/random_fetch.hip ->
 # profiles/r01d_random_fetch_microbench.txt): 115 G/s when the set is L2-resident, 57 G/s beyond L2
 L2_FETCH_CEILING_RESIDENT = 115.0e9
@@ -99,6 +100,7 @@ def useful_valu_share(kernel):
     if not k:
         return {"useful_valu_share": None}
     return {"useful_valu_share": k["useful_valu_share"], "valu_census": {x: k[x] for x in ("valu", "moves", "v_mov", "v_cndmask", "lane_spill", "div", "salu")},
+            "valu_census_issue_cycles_static_mix": k.get("valu_issue_cycles_static_mix"),
             "valu_census_measured_on_this_build": census.get("source_hash") == source_hash()}
 
 
@@ -439,6 +441,17 @@ def main():
                          **useful_valu_share(launch["kernel"]),
                          "note": "scene and sky tables live in SGPRs/LDS; HBM sees 12 B/pixel per frame (traffic), so the bound is VALU "
                                  "issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"})
+            # `peak` is the nominal rate.  MEASURED on this chip (profiles/r03_valu_issue.txt: tests/probes/microbench/valu_issue.hip,
+            # 2 and 4 waves per SIMD issuing nothing else): a plain VALU instruction holds its SIMD for 2.75 cycles, integer multiplies
+            # and packed-f32 for 4.5, v_rcp / v_sqrt for 8.25.  Against those, with the STATIC instruction mix of this kernel's binary
+            # (profiles/valu_census.json; cold paths included, so an estimate), the same `achieved` is:
+            mix = roof.get("valu_census_issue_cycles_static_mix")
+            roof["measured_issue_ceiling"] = {
+                "cycles_per_plain_instruction": VALU_PLAIN_CYCLES_MEASURED,
+                "frac_of_plain_instruction_ceiling": min(achieved / (VALU_ISSUE_PEAK * 2.0 / VALU_PLAIN_CYCLES_MEASURED), 1.0) if achieved else None,
+                "cycles_per_instruction_static_mix": mix,
+                "frac_of_static_mix_ceiling": min(achieved / (VALU_ISSUE_PEAK * 2.0 / mix), 1.0) if (achieved and mix) else None,
+                "source": "profiles/r03_valu_issue.txt + profiles/valu_census.json"}
         elif w["bound"] == "l2_request_rate":
             rps = counters.get("l2_read_requests_per_sample")
             hit = counters.get("l2_hit_rate")

@@ -63,6 +63,14 @@ def census(ops):
                div=fam('v_div_fixup_f32'), div64=fam('v_div_fixup_f64'), rcp=fam('v_rcp_f32'), sqrt=fam('v_sqrt_f32'), branches=sum(n for k, n in c.items() if k.startswith('s_cbranch')),
                saveexec=sum(n for k, n in c.items() if 'saveexec' in k))
     out['useful_valu_share'] = round(1.0 - moves / valu, 4) if valu else None
+    # issue-cost classes (profiles/r03_valu_issue.txt, tests/probes/microbench/valu_issue.hip, 4 waves per SIMD): a plain 32-bit
+    # VALU instruction occupies its SIMD for 2.75 cycles, 32-bit integer multiplies / v_mad_u64_u32 / packed-f32 for 4.5,
+    # v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos for 8.25
+    half = sum(n for k, n in c.items() if re.match(r'v_(mul_lo_u32|mul_lo_i32|mul_hi_u32|mul_hi_i32|mul_u32_u24|mul_i32_i24|mad_u32_u24|mad_i32_i24|mad_u64_u32|mad_i64_i32|pk_)', k))
+    trans = sum(n for k, n in c.items() if re.match(r'v_(rcp|rsq|sqrt|exp|log|sin|cos)_', k))
+    out['valu_half_rate'] = half
+    out['valu_transcendental'] = trans
+    out['valu_issue_cycles_static_mix'] = round(((valu - half - trans) * 2.75 + half * 4.5 + trans * 8.25) / valu, 4) if valu else None
     return out
 
 def write_committed_census():
