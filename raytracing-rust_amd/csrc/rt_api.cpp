@@ -342,8 +342,17 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 			s->feature_set = 0;
 		s->min_feature_set = s->feature_set;
 		if (h.dev_nodes.size() == 1 && (h.root_ref & kLeafFlag) == 0u) {
+			// FeatPair (rt_types.h): one node over two single-primitive leaves, both primitives Lambertian over a SolidColour,
+			// the sky's material an Emit (its texture is a SolidColour or a Lerp: no ctex in this feature set)
 			const DevNode &n0 = h.dev_nodes[0];
 			s->pair_tree = (n0.c0 & kLeafFlag) && (n0.c1 & kLeafFlag) && ((n0.c0 >> 26) & 31u) == 1u && ((n0.c1 >> 26) & 31u) == 1u;
+			for (const DevPrim &q : h.dev_prims) {
+				uint32_t meta;
+				std::memcpy(&meta, &q.a[3], sizeof meta);
+				const DevMaterial &m = h.materials[meta >> 2];
+				s->pair_tree = s->pair_tree && m.type == RT_MAT_LAMBERTIAN && m.tex_type == RT_TEX_SOLID;
+			}
+			s->pair_tree = s->pair_tree && h.materials[h.sky.material].type == RT_MAT_EMIT;
 		}
 	}
 	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice

@@ -570,6 +570,7 @@ __device__ __forceinline__ bool root_box_misses(const DevScene &S, const Ray &r)
 typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // (the pointer IS wave-uniform; where the compiler's divergence analysis cannot tell, this puts it into SGPRs -- and folds away where it can)
 template <class T> __device__ __forceinline__ const T *as_scalar_pointer(const T *p)
 {

@@ -298,6 +298,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	}
 
 	const bool sky_samplable = sky_can_sample(S);
+	constexpr int known_path = F::known_materials ? kMatLambertian : kMatRead; // the material a path continues from (see do_shade)
 
 	// ---- per-lane state (registers) ----
 	int ph = PH_NEED_PIXEL;
@@ -521,13 +522,16 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			make_hit<F>(S, prim, ray, best_t, nh, nmat);
 		else
 			make_sky_hit(S, nh, nmat);
+		// what is known of the two materials in play without reading them (rt_shade.h, kMatRead): the new hit's follows from
+		// what was hit; a path only ever continues from a material that is not a light
+		const int known_new = F::known_materials ? (prim == kNoPrim ? kMatEmit : kMatLambertian) : kMatRead;
 
 		if (METHOD == 0) {
 			// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
 			ray_count += 1;
 			const V3 wo_n = ray.d;
-			const V3 emission = mat_get_emission<F>(S, nmat, nh, wo_n);
-			const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng);
+			const V3 emission = emission_of_hit<F>(S, S_global, nmat, prim == kNoPrim, nh, wo_n);
+			const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng, known_new);
 			if (depth == 0) {
 				outp = outp + emission;
 				if (exit)
@@ -539,9 +543,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			}
 			if (!finish) {
 				if (!mat_is_delta<F>(S, nmat))
-					thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d);
+					thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d, known_new);
 				else
-					thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d);
+					thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d, known_new);
 				if (depth > P.rr_threshold) {
 					const float p = component_max(thr);
 					if (rt_rng_f32(&rng) > p)
@@ -560,9 +564,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			wo = ray.d;
 			hit = nh;
 			mat = nmat;
-			const V3 emission = mat_get_emission<F>(S, mat, hit, wo);
+			const V3 emission = emission_of_hit<F>(S, S_global, mat, prim == kNoPrim, hit, wo);
 			Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
-			const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng);
+			const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng, known_new);
 			outp = outp + emission;
 			if (exit) {
 				finish = true;
@@ -576,9 +580,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		} else {
 			// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
 			const V3 m_wi = ray.d;
-			const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi);
-			const V3 le = mat_get_emission<F>(S, nmat, hit /* the OLD hit, mis.rs:55 */, m_wi);
-			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi);
+			const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi, known_path);
+			const V3 le = emission_of_hit<F>(S, S_global, nmat, prim == kNoPrim, hit /* the OLD hit, mis.rs:55 */, m_wi);
+			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi, known_path);
 			if (!is_zero(le)) {
 				// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
 				// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
@@ -600,7 +604,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 					outp = outp + thr * le;
 				}
 			}
-			if (mat_is_light(S, nmat)) {
+			if (mat_is_light<F>(S, nmat, known_new)) {
 				finish = true;
 			} else {
 				if (depth > P.rr_threshold) {
@@ -688,7 +692,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			V3 le = v3s(0.0f);
 			float l_pdf = 0.0f;
 			if (L.shadow_is_sky) { // sample_sky  mis.rs:104-115
-				le = mat_get_emission<F>(S, S.sky.material, hit, L.l_wi);
+				le = emission_of_hit<F>(S, S_global, S.sky.material, true, hit, L.l_wi);
 				l_pdf = sky_pdf(S, T, L.l_wi) * L.pdf_multiplier;
 				valid = true;
 			} else { // sample_light  mis.rs:117-133 (`ray` still is the shadow ray)
@@ -704,15 +708,15 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				}
 			}
 			if (valid) { // mis.rs:39-43
-				const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, L.l_wi);
+				const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, L.l_wi, known_path);
 				const float mis_weight = power_heuristic(l_pdf, m_pdf);
-				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi) * mis_weight * le / l_pdf;
+				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi, known_path) * mis_weight * le / l_pdf;
 			}
 		}
 		// ---- material sampling  mis.rs:46-49.  scatter_ray reads only the incoming direction of
 		// the ray that produced `hit`, which is `wo` (mis.rs:21,82); `ray` held the shadow ray. ----
 		ray.d = wo;
-		if (mat_scatter_ray<F>(S, mat, ray, hit, rng))
+		if (mat_scatter_ray<F>(S, mat, ray, hit, rng, known_path))
 			finalize(true);
 		else
 			begin_walk(false);

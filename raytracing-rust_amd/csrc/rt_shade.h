@@ -180,9 +180,26 @@ template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &
 	return v3s(1.0f);
 }
 
-// the texture of material record `m`: SolidColour and Lerp are answered from the copy inside the record
-template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point)
+// What a caller may know about a material record without reading it.  The kernels compiled for a scene whose primitives all
+// carry a Lambertian with a SolidColour texture and whose sky is an Emit (F::known_materials: FeatPair, which the host picks
+// per launch only for such a scene, rt_api.cpp) pass the type that follows from WHAT WAS HIT -- a primitive: Lambertian, the
+// sky: Emit.  The record's type, its texture's type and the loads that only served to find them out are then gone: a material
+// evaluation was a chain of three dependent per-lane loads (type -> texture type -> colours), now it is one round of loads
+// (a Lambertian's colour and albedo) or none (scattering, pdf, "is it a light"), and the sky's record, the same for every
+// lane, arrives through scalar loads (sky_emission_uniform).  The arithmetic on what is read is untouched.
+enum : int { kMatRead = -1, kMatEmit = 0, kMatLambertian = 1 };
+template <class F> __device__ __forceinline__ int mat_type_(const DevMaterial &m, int known)
 {
+	if (F::known_materials && known != kMatRead)
+		return known;
+	return m.type;
+}
+
+// the texture of material record `m`: SolidColour and Lerp are answered from the copy inside the record
+template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point, int known = kMatRead)
+{
+	if (F::known_materials && known == kMatLambertian) // (its texture is a SolidColour: the host checked)
+		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
 	const int type = m.tex_type;
 	if (type == 1)
 		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
@@ -395,6 +412,7 @@ template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevM
 }
 
 __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return S.materials[mat].type == 0; }
+template <class F> __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat, int known) { return mat_type_<F>(S.materials[mat], known) == 0; }
 template <class F> __device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
 {
 	if (!F::cmat)
@@ -414,10 +432,10 @@ template <class F> __device__ __forceinline__ bool reflect_scatter(float fuzz, R
 }
 
 // Scatter::scatter_ray; returns `exit`
-template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng)
+template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng, int known = kMatRead)
 {
 	const DevMaterial &m = S.materials[mat];
-	const int type = m.type;
+	const int type = mat_type_<F>(m, known);
 	if (type == 1) { // Lambertian  lambertian.rs:30-41
 		const V3 direction = lambertian_sample(hit.normal, rng);
 		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
@@ -457,28 +475,30 @@ template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScen
 	return true;
 }
 
-template <class F> __device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
 {
 	const DevMaterial &m = S.materials[mat];
-	if (m.type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
+	const int type = mat_type_<F>(m, known);
+	if (type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
 		return fmax_(dot(wi, hit.normal), 0.0f) / kPi;
-	if (F::cmat && m.type == 2) { // trowbridge_reitz.rs:52-60
+	if (F::cmat && type == 2) { // trowbridge_reitz.rs:52-60
 		const float a = tr_pdf(m.param, -wo, wi, hit.normal);
 		return a == 0.0f ? INFINITY : a;
 	}
 	return 0.0f; // trait default (Reflect, Refract)
 }
 
-template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
 {
 	const DevMaterial &m = S.materials[mat];
-	if (m.type == 1) // lambertian.rs:45-47
-		return material_texture_colour<F>(S, m, wo, hit.point) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+	const int type = mat_type_<F>(m, known);
+	if (type == 1) // lambertian.rs:45-47
+		return material_texture_colour<F>(S, m, wo, hit.point, known) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
 	if (!F::cmat)
 		return v3s(0.0f);
-	if (m.type == 3 || m.type == 4) // reflect.rs:36-38, refract.rs:51-53
+	if (type == 3 || type == 4) // reflect.rs:36-38, refract.rs:51-53
 		return material_texture_colour<F>(S, m, wo, hit.point);
-	if (m.type == 2) { // trowbridge_reitz.rs:61-74
+	if (type == 2) { // trowbridge_reitz.rs:61-74
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
 		if (dot(wi, hit.normal) < 0.0f || dot(h, wom) < 0.0f)
@@ -491,14 +511,15 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 	return v3s(0.0f); // Emit::eval is unreachable!() in the reference
 }
 
-template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi)
+template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
 {
 	const DevMaterial &m = S.materials[mat];
-	if (m.type == 1) // lambertian.rs:48-50
-		return material_texture_colour<F>(S, m, wo, hit.point) * m.param;
+	const int type = mat_type_<F>(m, known);
+	if (type == 1) // lambertian.rs:48-50
+		return material_texture_colour<F>(S, m, wo, hit.point, known) * m.param;
 	if (!F::cmat)
 		return v3s(0.0f); // unreachable without Reflect/Refract/TrowbridgeReitz
-	if (m.type == 2) { // trowbridge_reitz.rs:75-87
+	if (type == 2) { // trowbridge_reitz.rs:75-87
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
 		if (dot(wom, h) < 0.0f || dot(wi, hit.normal) < 0.0f)
@@ -519,6 +540,40 @@ template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene
 		return m.param * material_texture_colour<F>(S, m, wo, point);
 	}
 	return v3s(0.0f);
+}
+// Emit::get_emission of the SKY's material when that record is known to be an Emit over a SolidColour or a Lerp
+// (F::known_materials): the record is the same for every lane, so it arrives through one round of scalar loads from the
+// scene as the kernel received it (SU: global memory nothing writes during the launch) and the colour is formed from SGPR
+// operands.  Neither texture reads the point, so offset_ray (emissive.rs:24) has nothing to feed.
+__device__ __forceinline__ V3 sky_emission_uniform(const DevScene &SU, V3 wo)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const DevMaterial *p = as_scalar_pointer(&SU.materials[SU.sky.material]);
+	u32x8_t a;
+	u32x2_t b;
+	asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+	const float param = __uint_as_float(a[2]);
+	const V3 c1 = v3(__uint_as_float(a[4]), __uint_as_float(a[5]), __uint_as_float(a[6]));
+	if (a[3] == 1u) // SolidColour (wave-uniform branch)
+		return param * c1;
+	const V3 c2 = v3(__uint_as_float(a[7]), __uint_as_float(b[0]), __uint_as_float(b[1]));
+	const float tt = wo.z * 0.5f + 0.5f; // Lerp  textures/mod.rs:283-291
+	return param * (c1 * tt + c2 * (1.0f - tt));
+#else
+	(void)SU; (void)wo;
+	return v3s(0.0f);
+#endif
+}
+// get_emission of what a path ray hit: a primitive's material or the sky's
+template <class F> __device__ __forceinline__ V3 emission_of_hit(const DevScene &S, const DevScene &SU, uint32_t mat, bool is_sky, const Hit &hit, V3 wo)
+{
+	if constexpr (F::known_materials) {
+		if (!is_sky)
+			return v3s(0.0f); // a Lambertian
+		return sky_emission_uniform(SU, wo);
+	} else {
+		return mat_get_emission<F>(S, mat, hit, wo);
+	}
 }
 
 // ---- light-sampling geometry of primitives ----

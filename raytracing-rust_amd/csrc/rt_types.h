@@ -31,14 +31,20 @@ template <bool TRI, bool LIGHTS, bool CMAT, bool CTEX> struct Feat {
 	static constexpr bool cmat = CMAT;     // Reflect / Refract / TrowbridgeReitz materials
 	static constexpr bool ctex = CTEX;     // Checkered / Image / Perlin textures
 	static constexpr bool pair = false;    // (see FeatPair)
+	static constexpr bool known_materials = false; // (see FeatPair)
 };
 using FeatFull = Feat<true, true, true, true>;
 // The smallest set plus one fact about the TREE: one inner node over two leaves of one primitive each (scenes/rtweekend1.ssml:
 // the ground and one sphere).  The walk is then two box tests and two sphere tests on records that arrive through one
 // round of scalar loads (rt_intersect.h), and with the general walk not even compiled in the coarse kernels need no
 // spilled register (profiles/resource_table.json).  Chosen by the host per launch (rt_api.cpp), like every other set.
+// ... and one fact about its MATERIALS: both primitives carry a Lambertian over a SolidColour and the sky's material is an
+// Emit (what the loader makes of `sky ( texture ... )`).  A material's type then follows from what a ray hit, and the
+// dependent loads that only looked it up are not compiled in (rt_shade.h, kMatRead).  A two-leaf scene with other materials
+// runs the spheres-only set, which walks such a tree the same way.
 struct FeatPair : Feat<false, false, false, false> {
 	static constexpr bool pair = true;
+	static constexpr bool known_materials = true;
 };
 
 // child reference: bit 31 clear = inner node index; bit 31 set = leaf, bits 26-30 primitive count
