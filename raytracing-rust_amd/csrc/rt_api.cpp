@@ -31,7 +31,7 @@ size_t render_exchange_lds_bytes(uint32_t slots);
 uint32_t render_exchange_max_slots();
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg);
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
@@ -97,6 +97,7 @@ struct rt_scene {
 	// the tree is one inner node over two leaves of one primitive each: launches that would run the spheres-only exhaustive
 	// coarse kernels run their FeatPair twins (rt_types.h) -- unless a feature set was asked for by name (RT_TUNE_FEATURE_SET)
 	bool pair_tree = false, feature_set_forced = false;
+	DevPairScene pair{}; // pair_tree: the scene as the FeatPair kernels take it, in their kernel arguments (rt_types.h)
 	bool scene_lds_allowed = true;
 	float *d_partial = nullptr; // sample_split > 1: per-chunk means, grown on demand
 	size_t partial_floats = 0;
@@ -353,6 +354,29 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 				s->pair_tree = s->pair_tree && m.type == RT_MAT_LAMBERTIAN && m.tex_type == RT_TEX_SOLID;
 			}
 			s->pair_tree = s->pair_tree && h.materials[h.sky.material].type == RT_MAT_EMIT;
+			if (s->pair_tree) { // ... and that scene as kernel arguments, copied from the very records the other kernels read
+				DevPairScene &q = s->pair;
+				std::memcpy(q.c0min, n0.c0min, sizeof q.c0min); std::memcpy(q.c0max, n0.c0max, sizeof q.c0max);
+				std::memcpy(q.c1min, n0.c1min, sizeof q.c1min); std::memcpy(q.c1max, n0.c1max, sizeof q.c1max);
+				q.slot0 = n0.c0 & kLeafSlotMask;
+				q.slot1 = n0.c1 & kLeafSlotMask;
+				q.rank0 = h.prim_rank[q.slot0];
+				q.rank1 = h.prim_rank[q.slot1];
+				const uint32_t slots[2] = {q.slot0, q.slot1};
+				for (int k = 0; k < 2; ++k) {
+					const DevPrim &pr = h.dev_prims[slots[k]];
+					uint32_t meta;
+					std::memcpy(&meta, &pr.a[3], sizeof meta);
+					const DevMaterial &m = h.materials[meta >> 2];
+					q.sphere[k][0] = pr.a[0]; q.sphere[k][1] = pr.a[1]; q.sphere[k][2] = pr.a[2]; q.sphere[k][3] = pr.b[0];
+					q.lambert[k][0] = m.tex_c1[0]; q.lambert[k][1] = m.tex_c1[1]; q.lambert[k][2] = m.tex_c1[2]; q.lambert[k][3] = m.param;
+				}
+				const DevMaterial &sky = h.materials[h.sky.material];
+				q.sky_param = sky.param;
+				q.sky_tex_type = sky.tex_type;
+				std::memcpy(q.sky_c1, sky.tex_c1, sizeof q.sky_c1);
+				std::memcpy(q.sky_c2, sky.tex_c2, sizeof q.sky_c2);
+			}
 		}
 	}
 	if (const char *e = std::getenv("RT_HIP_TRAVERSAL")) { // "exhaustive" | "pruned": override the automatic choice
@@ -1150,7 +1174,8 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	}
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
 	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, feature_set, (uint32_t)n_blocks, lds_bytes, stream, dev, cam, P, render_target,
-	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg));
+	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg,
+	                      feature_set == 3 ? &s->pair : nullptr));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
 		HIP_TRY(launch_combine(stream, P, s->d_partial, d_out_rgb));

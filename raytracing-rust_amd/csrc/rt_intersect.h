@@ -260,27 +260,42 @@ __device__ __forceinline__ bool check_side(V3 &normal, V3 ray_direction)
 // for the primitive that won the traversal.  `t` is the value the traversal computed for it; a
 // sphere needs nothing else, a triangle re-runs its intersector for the barycentrics (same code and
 // inputs, so the same t).
-template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, uint32_t slot, const Ray &r, float t_known, Hit &h, uint32_t &material)
+__device__ __forceinline__ void make_sphere_hit(V3 centre, float radius, const Ray &r, float t, Hit &h) // sphere.rs:79-101
 {
+	const V3 point = r.o + r.d * t;
+	V3 normal = (point - centre) / radius;
+	bool out = true;
+	if (dot(normal, r.d) > 0.0f) {
+		out = false;
+		normal = -normal;
+	}
+	h.t = t;
+	h.point = point;
+	h.error = kEpsilon * v3s(1.0f);
+	h.normal = normal;
+	h.err_dot = dot(vabs(normal), h.error);
+	h.uvx = h.uvy = 0.0f;
+	h.has_uv = false; // no material overrides Scatter::requires_uv (rt_core/src/material.rs:8-10)
+	h.out = out;
+}
+template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, uint32_t slot, const Ray &r, float t_known, Hit &h, uint32_t &material,
+                                                            const DevPairScene &ps = kNoPairScene)
+{
+	if constexpr (F::pair) {
+		// the sphere's record from the kernel arguments (rt_types.h DevPairScene), selected by the slot; the "material" the
+		// pair kernels carry along a path is the slot itself: all they ever want of it is the Lambertian record, which
+		// lies next to the sphere's (rt_shade.h known_lambert)
+		const bool first = slot == ps.slot0;
+		const V3 centre = first ? v3(ps.sphere[0][0], ps.sphere[0][1], ps.sphere[0][2]) : v3(ps.sphere[1][0], ps.sphere[1][1], ps.sphere[1][2]);
+		const float radius = first ? ps.sphere[0][3] : ps.sphere[1][3];
+		material = slot;
+		make_sphere_hit(centre, radius, r, t_known, h);
+		return;
+	}
 	const PrimGeom g = load_prim<F>(S, slot);
 	material = g.material;
 	if (!F::tri || g.type == kPrimSphere) {
-		const float t = t_known;
-		const V3 point = r.o + r.d * t;
-		V3 normal = (point - g.p0) / g.p1.x;
-		bool out = true;
-		if (dot(normal, r.d) > 0.0f) {
-			out = false;
-			normal = -normal;
-		}
-		h.t = t;
-		h.point = point;
-		h.error = kEpsilon * v3s(1.0f);
-		h.normal = normal;
-		h.err_dot = dot(vabs(normal), h.error);
-		h.uvx = h.uvy = 0.0f;
-		h.has_uv = false; // no material overrides Scatter::requires_uv (rt_core/src/material.rs:8-10)
-		h.out = out;
+		make_sphere_hit(g.p0, g.p1.x, r, t_known, h);
 		return;
 	}
 	float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
@@ -725,26 +740,46 @@ __device__ __forceinline__ bool any_in_leaf(const DevScene &S, const Ray &r, uin
 __device__ __forceinline__ bool is_two_leaf_tree(const DevScene &S) { return S.n_nodes == 1u && !ref_is_leaf(S.root_ref); }
 
 // Bvh::check_hit: smallest t > 0, ties to the primitive first in BFS-leaf order (mod.rs:265-298)
+// FeatPair: the node's two boxes from the kernel arguments (rt_types.h DevPairScene)
+struct PairBoxes {
+	float c0min[3], c0max[3], c1min[3], c1max[3];
+};
+__device__ __forceinline__ PairBoxes pair_boxes(const DevPairScene &ps)
+{
+	PairBoxes b;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		b.c0min[k] = ps.c0min[k]; b.c0max[k] = ps.c0max[k];
+		b.c1min[k] = ps.c1min[k]; b.c1max[k] = ps.c1max[k];
+	}
+	return b;
+}
+
 template <class F, bool PRUNE, bool OVF = false>
 __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float &best_t,
-                                              uint32_t &best_prim)
+                                              uint32_t &best_prim, const DevPairScene &ps = kNoPairScene)
 {
 	best_t = 0.0f;
 	best_prim = kNoPrim;
-	if (root_box_misses(S, r))
+	if (!F::pair && root_box_misses(S, r)) // (FeatPair: the root is an inner node)
 		return;
 	if constexpr (F::pair) { // the host launches this set only for such a tree: nothing else is compiled in
-		const NodeView n = load_node_uniform(SU.nodes);
+		// both child boxes, then the leaves whose box was hit, in the reference's candidate order; the selection rule of
+		// Bvh::check_hit (mod.rs:270-293) for two candidates: smallest t > 0, an exact tie to the first in BFS-leaf order
+		const PairBoxes n = pair_boxes(ps);
 		float t0, t1, t;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
-		const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
-		PrimGeom g0, g1;
-		load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
-		if (h0 && prim_t<F>(g0, r, t) && t > 0.0f)
-			consider_closest(SU, s0, t, best_t, best_prim);
-		if (h1 && prim_t<F>(g1, r, t) && t > 0.0f)
-			consider_closest(SU, s1, t, best_t, best_prim);
+		if (h0 && sphere_t(v3(ps.sphere[0][0], ps.sphere[0][1], ps.sphere[0][2]), ps.sphere[0][3], r, t) && t > 0.0f) {
+			best_t = t;
+			best_prim = ps.slot0;
+		}
+		if (h1 && sphere_t(v3(ps.sphere[1][0], ps.sphere[1][1], ps.sphere[1][2]), ps.sphere[1][3], r, t) && t > 0.0f) {
+			if (best_prim == kNoPrim || t < best_t || (t == best_t && ps.rank1 < ps.rank0)) {
+				best_t = t;
+				best_prim = ps.slot1;
+			}
+		}
 		return;
 	}
 	if (!PRUNE && is_two_leaf_tree(S)) {
@@ -796,22 +831,20 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 // limit" (any t > 0 occludes).
 template <class F, bool PRUNE, bool OVF = false>
 __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU, const StackMem &M, const Ray &r, uint32_t *stk, float t_limit,
-                                          uint32_t skip)
+                                          uint32_t skip, const DevPairScene &ps = kNoPairScene)
 {
-	if (root_box_misses(S, r))
+	if (!F::pair && root_box_misses(S, r))
 		return false;
 	const bool limited = !(t_limit != t_limit);
 	if constexpr (F::pair) { // as in trace_closest
-		const NodeView n = load_node_uniform(SU.nodes);
+		const PairBoxes n = pair_boxes(ps);
 		float t0, t1, t;
 		const bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 		const bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
-		const uint32_t s0 = n.c0 & kLeafSlotMask, s1 = n.c1 & kLeafSlotMask;
-		PrimGeom g0, g1;
-		load_prim_pair_uniform<F>(&SU.prims[s0], &SU.prims[s1], g0, g1);
-		if (h0 && s0 != skip && prim_t<F>(g0, r, t) && t > 0.0f && !(t >= t_limit))
+		if (h0 && ps.slot0 != skip && sphere_t(v3(ps.sphere[0][0], ps.sphere[0][1], ps.sphere[0][2]), ps.sphere[0][3], r, t) && t > 0.0f && !(t >= t_limit))
 			return true;
-		return h1 && s1 != skip && prim_t<F>(g1, r, t) && t > 0.0f && !(t >= t_limit);
+		return h1 && ps.slot1 != skip && sphere_t(v3(ps.sphere[1][0], ps.sphere[1][1], ps.sphere[1][2]), ps.sphere[1][3], r, t) && t > 0.0f &&
+		       !(t >= t_limit);
 	}
 	if (!PRUNE && is_two_leaf_tree(S)) {
 		const NodeView n = load_node_uniform(SU.nodes);

@@ -193,6 +193,7 @@ struct RenderArgs {
 	unsigned long long *rays_shot;
 	uint32_t *work_counter;
 	uint32_t *stack_ovf;
+	DevPairScene pair; // FeatPair only (rt_types.h): the whole scene, read where it is used
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) RenderArgs *KArgs; // the kernarg segment is constant memory: s_load
@@ -220,6 +221,28 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	const KArgs K = &args_by_value;
 	auto kargs = [&]() -> KArgs { return K; };
 #endif
+	// FeatPair: the scene in scalar registers for the length of a super-phase -- read from the kernel arguments in ONE round of
+	// scalar loads at its top (rt_types.h DevPairScene), by the walks, make_hit and the material evaluations after that
+	DevPairScene PS = {};
+	auto load_pair_scene = [&]() {
+		if constexpr (F::pair) {
+			const KArgs k = kargs();
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				PS.c0min[i] = k->pair.c0min[i]; PS.c0max[i] = k->pair.c0max[i];
+				PS.c1min[i] = k->pair.c1min[i]; PS.c1max[i] = k->pair.c1max[i];
+				PS.sky_c1[i] = k->pair.sky_c1[i]; PS.sky_c2[i] = k->pair.sky_c2[i];
+			}
+			PS.slot0 = k->pair.slot0; PS.slot1 = k->pair.slot1; PS.rank0 = k->pair.rank0; PS.rank1 = k->pair.rank1;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				PS.sphere[0][i] = k->pair.sphere[0][i]; PS.sphere[1][i] = k->pair.sphere[1][i];
+				PS.lambert[0][i] = k->pair.lambert[0][i]; PS.lambert[1][i] = k->pair.lambert[1][i];
+			}
+			PS.sky_param = k->pair.sky_param;
+			PS.sky_tex_type = k->pair.sky_tex_type;
+		}
+	};
 	// (Passing the node / primitive / rank arrays of the two-leaf walk as separate `const __restrict__` kernel arguments turns
 	// its loads back into scalar loads -- through this struct they are vector loads of a uniform address -- but measured nothing
 	// on configs 2 and 3 and cost the fine MIS kernels 10 % (1 M triangles 50.1 -> 55.5 ms, same-box A/B): three more
@@ -519,7 +542,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		Hit nh;
 		uint32_t nmat;
 		if (prim != kNoPrim)
-			make_hit<F>(S, prim, ray, best_t, nh, nmat);
+			make_hit<F>(S, prim, ray, best_t, nh, nmat, PS);
 		else
 			make_sky_hit(S, nh, nmat);
 		// what is known of the two materials in play without reading them (rt_shade.h, kMatRead): the new hit's follows from
@@ -530,7 +553,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			// ---- NaiveIntegrator::get_colour loop body  integrators/mod.rs:31-72 ----
 			ray_count += 1;
 			const V3 wo_n = ray.d;
-			const V3 emission = emission_of_hit<F>(S, S_global, nmat, prim == kNoPrim, nh, wo_n);
+			const V3 emission = emission_of_hit<F>(S, PS, nmat, prim == kNoPrim, nh, wo_n);
 			const bool exit = mat_scatter_ray<F>(S, nmat, ray, nh, rng, known_new);
 			if (depth == 0) {
 				outp = outp + emission;
@@ -543,9 +566,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			}
 			if (!finish) {
 				if (!mat_is_delta<F>(S, nmat))
-					thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d, known_new);
+					thr = thr * mat_eval_over_pdf<F>(S, nmat, nh, wo_n, ray.d, known_new, PS);
 				else
-					thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d, known_new);
+					thr = thr * mat_eval<F>(S, nmat, nh, wo_n, ray.d, known_new, PS);
 				if (depth > P.rr_threshold) {
 					const float p = component_max(thr);
 					if (rt_rng_f32(&rng) > p)
@@ -564,7 +587,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			wo = ray.d;
 			hit = nh;
 			mat = nmat;
-			const V3 emission = emission_of_hit<F>(S, S_global, mat, prim == kNoPrim, hit, wo);
+			const V3 emission = emission_of_hit<F>(S, PS, mat, prim == kNoPrim, hit, wo);
 			Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
 			const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng, known_new);
 			outp = outp + emission;
@@ -581,8 +604,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			// ---- material-sampling half of the MIS loop  mis.rs:50-86 ----
 			const V3 m_wi = ray.d;
 			const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi, known_path);
-			const V3 le = emission_of_hit<F>(S, S_global, nmat, prim == kNoPrim, hit /* the OLD hit, mis.rs:55 */, m_wi);
-			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi, known_path);
+			const V3 le = emission_of_hit<F>(S, PS, nmat, prim == kNoPrim, hit /* the OLD hit, mis.rs:55 */, m_wi);
+			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi, known_path, PS);
 			if (!is_zero(le)) {
 				// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
 				// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
@@ -692,7 +715,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			V3 le = v3s(0.0f);
 			float l_pdf = 0.0f;
 			if (L.shadow_is_sky) { // sample_sky  mis.rs:104-115
-				le = emission_of_hit<F>(S, S_global, S.sky.material, true, hit, L.l_wi);
+				le = emission_of_hit<F>(S, PS, S.sky.material, true, hit, L.l_wi);
 				l_pdf = sky_pdf(S, T, L.l_wi) * L.pdf_multiplier;
 				valid = true;
 			} else { // sample_light  mis.rs:117-133 (`ray` still is the shadow ray)
@@ -710,7 +733,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			if (valid) { // mis.rs:39-43
 				const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, L.l_wi, known_path);
 				const float mis_weight = power_heuristic(l_pdf, m_pdf);
-				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi, known_path) * mis_weight * le / l_pdf;
+				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi, known_path, PS) * mis_weight * le / l_pdf;
 			}
 		}
 		// ---- material sampling  mis.rs:46-49.  scatter_ray reads only the incoming direction of
@@ -741,13 +764,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	// of rt_intersect.h (closest walk in the TRACE super-phase, shadow walk in the LIGHT super-phase)
 	auto walk_closest_pending = [&]() {
 		if (ph == PH_NODE && !any_hit) {
-			trace_closest<F, PRUNE>(S, S_global, SM, ray, stk, best_t, best_prim);
+			trace_closest<F, PRUNE>(S, S_global, SM, ray, stk, best_t, best_prim, PS);
 			ph = PH_SHADE;
 		}
 	};
 	auto walk_shadow_pending = [&](const LightCtx &L, const Ray &sr) {
 		if (ph == PH_NODE && any_hit) {
-			best_prim = trace_any<F, PRUNE>(S, S_global, SM, sr, stk, L.t_limit, L.skip) ? 0u : kNoPrim;
+			best_prim = trace_any<F, PRUNE>(S, S_global, SM, sr, stk, L.t_limit, L.skip, PS) ? 0u : kNoPrim;
 			ph = PH_SCATTER;
 		}
 	};
@@ -1258,6 +1281,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				if (!run_light) {
 					if (kFuseRegions) {
 						if (ph == PH_GEN) {
+							load_pair_scene();
 							do_gen();
 							RT_SECTION(1);
 							walk_closest_pending();
@@ -1275,6 +1299,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 						}
 	#endif
 					} else {
+						load_pair_scene();
 						if (ph == PH_GEN)
 							do_gen();
 						RT_SECTION(1);
@@ -1296,6 +1321,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 					sray.o = sray.d = sray.inv = sray.shear = v3s(0.0f);
 					if (kFuseRegions) {
 						if (ph == PH_LIGHT) {
+							load_pair_scene();
 							do_light(L, sray);
 							RT_SECTION(4);
 							walk_shadow_pending(L, sray);
@@ -1310,6 +1336,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 						}
 						RT_SECTION(8);
 					} else {
+						load_pair_scene();
 						if (ph == PH_LIGHT)
 							do_light(L, sray);
 						RT_SECTION(4);
@@ -1964,7 +1991,7 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg)
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair)
 {
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
@@ -1977,6 +2004,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
 	A.rays_shot = rays_shot;
 	A.work_counter = work_counter;
 	A.stack_ovf = stack_ovf;
+	A.pair = pair ? *pair : DevPairScene{};
 	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, A);
 	return hipGetLastError();
 }

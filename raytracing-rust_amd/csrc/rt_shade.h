@@ -196,10 +196,8 @@ template <class F> __device__ __forceinline__ int mat_type_(const DevMaterial &m
 }
 
 // the texture of material record `m`: SolidColour and Lerp are answered from the copy inside the record
-template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point, int known = kMatRead)
+template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point)
 {
-	if (F::known_materials && known == kMatLambertian) // (its texture is a SolidColour: the host checked)
-		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
 	const int type = m.tex_type;
 	if (type == 1)
 		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
@@ -210,6 +208,27 @@ template <class F> __device__ __forceinline__ V3 material_texture_colour(const D
 	if (!F::ctex)
 		return v3s(1.0f); // unreachable: see texture_colour
 	return texture_colour<F>(S, m.texture, direction, point);
+}
+
+// texture colour and albedo of a Lambertian: read from its record, or -- F::known_materials -- selected between the two
+// records in the kernel arguments by the slot the pair kernels carry as "material" (rt_intersect.h make_hit, rt_types.h
+// DevPairScene): SGPR operands and two selects per value instead of a per-lane load
+struct LambertRec {
+	V3 colour;
+	float albedo;
+};
+template <class F> __device__ __forceinline__ LambertRec lambert_record(const DevScene &S, const DevMaterial &m, uint32_t mat, V3 direction, V3 point, const DevPairScene &ps)
+{
+	LambertRec L;
+	if constexpr (F::known_materials) {
+		const bool first = mat == ps.slot0;
+		L.colour = first ? v3(ps.lambert[0][0], ps.lambert[0][1], ps.lambert[0][2]) : v3(ps.lambert[1][0], ps.lambert[1][1], ps.lambert[1][2]);
+		L.albedo = first ? ps.lambert[0][3] : ps.lambert[1][3];
+	} else {
+		L.colour = material_texture_colour<F>(S, m, direction, point);
+		L.albedo = m.param;
+	}
+	return L;
 }
 
 // A wave-uniform value the optimiser must not see through: conversions and products of it are then computed where they are used
@@ -488,12 +507,14 @@ template <class F> __device__ __forceinline__ float mat_scattering_pdf(const Dev
 	return 0.0f; // trait default (Reflect, Refract)
 }
 
-template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
+template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead, const DevPairScene &ps = kNoPairScene)
 {
 	const DevMaterial &m = S.materials[mat];
 	const int type = mat_type_<F>(m, known);
-	if (type == 1) // lambertian.rs:45-47
-		return material_texture_colour<F>(S, m, wo, hit.point, known) * m.param * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+	if (type == 1) { // lambertian.rs:45-47
+		const LambertRec L = lambert_record<F>(S, m, mat, wo, hit.point, ps);
+		return L.colour * L.albedo * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+	}
 	if (!F::cmat)
 		return v3s(0.0f);
 	if (type == 3 || type == 4) // reflect.rs:36-38, refract.rs:51-53
@@ -511,12 +532,14 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 	return v3s(0.0f); // Emit::eval is unreachable!() in the reference
 }
 
-template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
+template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead, const DevPairScene &ps = kNoPairScene)
 {
 	const DevMaterial &m = S.materials[mat];
 	const int type = mat_type_<F>(m, known);
-	if (type == 1) // lambertian.rs:48-50
-		return material_texture_colour<F>(S, m, wo, hit.point, known) * m.param;
+	if (type == 1) { // lambertian.rs:48-50
+		const LambertRec L = lambert_record<F>(S, m, mat, wo, hit.point, ps);
+		return L.colour * L.albedo;
+	}
 	if (!F::cmat)
 		return v3s(0.0f); // unreachable without Reflect/Refract/TrowbridgeReitz
 	if (type == 2) { // trowbridge_reitz.rs:75-87
@@ -542,35 +565,25 @@ template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene
 	return v3s(0.0f);
 }
 // Emit::get_emission of the SKY's material when that record is known to be an Emit over a SolidColour or a Lerp
-// (F::known_materials): the record is the same for every lane, so it arrives through one round of scalar loads from the
-// scene as the kernel received it (SU: global memory nothing writes during the launch) and the colour is formed from SGPR
-// operands.  Neither texture reads the point, so offset_ray (emissive.rs:24) has nothing to feed.
-__device__ __forceinline__ V3 sky_emission_uniform(const DevScene &SU, V3 wo)
+// (F::known_materials): strength, texture type and colours come from the kernel arguments (rt_types.h DevPairScene) and the
+// colour is formed from SGPR operands.  Neither texture reads the point, so offset_ray (emissive.rs:24) has nothing to feed.
+__device__ __forceinline__ V3 sky_emission_uniform(const DevPairScene &ps, V3 wo)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-	const DevMaterial *p = as_scalar_pointer(&SU.materials[SU.sky.material]);
-	u32x8_t a;
-	u32x2_t b;
-	asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
-	const float param = __uint_as_float(a[2]);
-	const V3 c1 = v3(__uint_as_float(a[4]), __uint_as_float(a[5]), __uint_as_float(a[6]));
-	if (a[3] == 1u) // SolidColour (wave-uniform branch)
+	const float param = ps.sky_param;
+	const V3 c1 = v3(ps.sky_c1[0], ps.sky_c1[1], ps.sky_c1[2]);
+	if (ps.sky_tex_type == 1) // SolidColour (wave-uniform branch)
 		return param * c1;
-	const V3 c2 = v3(__uint_as_float(a[7]), __uint_as_float(b[0]), __uint_as_float(b[1]));
+	const V3 c2 = v3(ps.sky_c2[0], ps.sky_c2[1], ps.sky_c2[2]);
 	const float tt = wo.z * 0.5f + 0.5f; // Lerp  textures/mod.rs:283-291
 	return param * (c1 * tt + c2 * (1.0f - tt));
-#else
-	(void)SU; (void)wo;
-	return v3s(0.0f);
-#endif
 }
 // get_emission of what a path ray hit: a primitive's material or the sky's
-template <class F> __device__ __forceinline__ V3 emission_of_hit(const DevScene &S, const DevScene &SU, uint32_t mat, bool is_sky, const Hit &hit, V3 wo)
+template <class F> __device__ __forceinline__ V3 emission_of_hit(const DevScene &S, const DevPairScene &ps, uint32_t mat, bool is_sky, const Hit &hit, V3 wo)
 {
 	if constexpr (F::known_materials) {
 		if (!is_sky)
 			return v3s(0.0f); // a Lambertian
-		return sky_emission_uniform(SU, wo);
+		return sky_emission_uniform(ps, wo);
 	} else {
 		return mat_get_emission<F>(S, mat, hit, wo);
 	}

@@ -175,6 +175,31 @@ struct DevScene {
 	DevSky sky;
 };
 
+// FeatPair's scene as KERNEL ARGUMENTS (rt_render.hip RenderArgs::pair): one node, two spheres, two Lambertian records and
+// the sky's Emit are 40 dwords that are the same for every lane of every wave.  A super-phase of the coarse schedule reads
+// them from the kernarg segment in ONE round of scalar loads at its top (load_pair_scene) and its walks, make_hit and
+// material evaluations take them from SGPRs -- instead of chasing them through the scene's arrays (node -> slots ->
+// primitive records -> material records: two dependent rounds of scalar loads per walk, a per-lane load per hit record and
+// per material evaluation).  Everything is in CHILD order (entry 0 belongs to the node's first child, the first candidate
+// of Bvh::get_intersection_candidates): a per-lane slot selects between the two entries by `slot == slot0`.  Filled by the
+// host from the arrays the other kernels read (rt_api.cpp), so both routes see the same bits.  Measured same-box at 256
+// spp: 24.0 -> 23.55 ms; the same block read through the kernarg pointer at each use (seven rounds per iteration instead of
+// two) measured 24.2 (gpurun_out/r05b, r05c).
+struct alignas(64) DevPairScene {
+	float c0min[3], c0max[3], c1min[3], c1max[3]; // DevNode's child boxes
+	uint32_t slot0, slot1;                        // primitive slot of each leaf
+	uint32_t rank0, rank1;                        // DevScene::prim_rank of those slots (exact-t ties)
+	float sphere[2][4];                           // centre.xyz, radius
+	float lambert[2][4];                          // SolidColour rgb, albedo (Lambertian::param)
+	float sky_param;                              // the sky's Emit: strength,
+	int32_t sky_tex_type;                         // its texture (SolidColour or Lerp)
+	float sky_c1[3], sky_c2[3];
+	uint32_t pad[8];
+};
+static_assert(sizeof(DevPairScene) == 192, "DevPairScene: three 64-byte lines");
+// (what the kernels of every other feature set pass where a pair scene is expected: never read)
+__device__ static const DevPairScene kNoPairScene = {};
+
 struct DevCamera {
 	float origin[3], lower_left[3], horizontal[3], vertical[3];
 };

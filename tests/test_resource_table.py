@@ -55,9 +55,8 @@ def test_headline_kernels_hold_their_budgets(built_table):
     assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 14
     assert spheres["sgpr_spill_count"] <= 24
     # the kernel BASELINE config 2 itself runs (rtweekend1's tree is one node over two single-sphere leaves: rt_types.h FeatPair,
-    # the general walk not compiled in, material types known from what was hit): no spilled vector register, no scratch, and
-    # at most a handful of scalars parked in VGPR lanes (2 with the known material types: 5.6 % faster than the build with
-    # none, same-box A/B gpurun_out/r05a)
+    # the general walk not compiled in, material types known from what was hit, the scene itself read from the kernel
+    # arguments once per super-phase): no spilled register of either kind, no scratch
     pair = built_table["void rt::render_kernel<1, false, false, true, rt::FeatPair, false>"]
     assert pair["waves_per_simd_by_registers"] >= 4
-    assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] <= 4
+    assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] == 0
