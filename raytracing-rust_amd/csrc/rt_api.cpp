@@ -311,7 +311,7 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 	s->stack_depth_narrow = h.stack_depth_narrow;
 	D.has_triangles = h.has_triangles ? 1u : 0u;
 	D.sky.texture = h.sky.texture;
-	D.sky.material = h.sky.material;
+	D.sky.material = mat_handle_make(h.sky.material, h.materials[h.sky.material].type, h.materials[h.sky.material].tex_type);
 	D.sky.res_x = h.sky.sampler_res_x;
 	D.sky.res_y = h.sky.sampler_res_y;
 	D.sky.row_cdf = d_sky;
@@ -350,7 +350,7 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 			for (const DevPrim &q : h.dev_prims) {
 				uint32_t meta;
 				std::memcpy(&meta, &q.a[3], sizeof meta);
-				const DevMaterial &m = h.materials[meta >> 2];
+				const DevMaterial &m = h.materials[mat_handle_index(meta >> 2)];
 				s->pair_tree = s->pair_tree && m.type == RT_MAT_LAMBERTIAN && m.tex_type == RT_TEX_SOLID;
 			}
 			s->pair_tree = s->pair_tree && h.materials[h.sky.material].type == RT_MAT_EMIT;
@@ -367,7 +367,7 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 					const DevPrim &pr = h.dev_prims[slots[k]];
 					uint32_t meta;
 					std::memcpy(&meta, &pr.a[3], sizeof meta);
-					const DevMaterial &m = h.materials[meta >> 2];
+					const DevMaterial &m = h.materials[mat_handle_index(meta >> 2)];
 					q.sphere[k][0] = pr.a[0]; q.sphere[k][1] = pr.a[1]; q.sphere[k][2] = pr.a[2]; q.sphere[k][3] = pr.b[0];
 					q.lambert[k][0] = m.tex_c1[0]; q.lambert[k][1] = m.tex_c1[1]; q.lambert[k][2] = m.tex_c1[2]; q.lambert[k][3] = m.param;
 				}

@@ -434,6 +434,10 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			o.tex_c2[k] = t.c2[k];
 		}
 	}
+	if (d->n_materials >= kMatMaxCount) { // (a primitive record carries the material as a 24-bit index + type tags: rt_types.h)
+		err = "more than 2^24 - 1 materials";
+		return RT_ERR_UNSUPPORTED;
+	}
 	if (d->sky.texture >= d->n_textures || d->sky.material >= d->n_materials) {
 		err = "sky texture/material index out of range";
 		return RT_ERR_INVALID_ARGUMENT;
@@ -542,7 +546,8 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			s.n1[0] = nn[1].x; s.n1[1] = nn[1].y; s.n1[2] = nn[1].z;
 			s.n2[0] = nn[2].x; s.n2[1] = nn[2].y; s.n2[2] = nn[2].z;
 		}
-		const uint32_t meta = type | (p.material << 2);
+		const DevMaterial &pm = hs.materials[p.material];
+		const uint32_t meta = type | (mat_handle_make(p.material, pm.type, pm.tex_type) << 2);
 		std::memcpy(&o.a[3], &meta, 4);
 	}
 	});

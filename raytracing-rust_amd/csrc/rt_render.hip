@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void store_record(DevHitRecord &o, const Hit &h, uint
 	o.uv[0] = h.uvx; o.uv[1] = h.uvy;
 	o.has_uv = h.has_uv ? 1 : 0;
 	o.out = h.out ? 1 : 0;
-	o.material = material;
+	o.material = mat_handle_index(material); // (the caller's index, not the handle the kernels carry)
 	o.found = found ? 1u : 0u;
 	o.index = index;
 }

@@ -188,17 +188,19 @@ template <class F> __device__ __forceinline__ V3 texture_colour(const DevScene &
 // (a Lambertian's colour and albedo) or none (scattering, pdf, "is it a light"), and the sky's record, the same for every
 // lane, arrives through scalar loads (sky_emission_uniform).  The arithmetic on what is read is untouched.
 enum : int { kMatRead = -1, kMatEmit = 0, kMatLambertian = 1 };
-template <class F> __device__ __forceinline__ int mat_type_(const DevMaterial &m, int known)
+// (`mat` is a handle, rt_types.h kMatHandleShift: the type rides in it)
+template <class F> __device__ __forceinline__ int mat_type_(uint32_t mat, int known)
 {
 	if (F::known_materials && known != kMatRead)
 		return known;
-	return m.type;
+	return mat_handle_type(mat);
 }
+__device__ __forceinline__ const DevMaterial &mat_record(const DevScene &S, uint32_t mat) { return S.materials[mat_handle_index(mat)]; }
 
 // the texture of material record `m`: SolidColour and Lerp are answered from the copy inside the record
-template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, V3 direction, V3 point)
+template <class F> __device__ __forceinline__ V3 material_texture_colour(const DevScene &S, const DevMaterial &m, uint32_t mat, V3 direction, V3 point)
 {
-	const int type = m.tex_type;
+	const int type = mat_handle_tex_type(mat);
 	if (type == 1)
 		return v3(m.tex_c1[0], m.tex_c1[1], m.tex_c1[2]);
 	if (type == 3) {
@@ -225,7 +227,7 @@ template <class F> __device__ __forceinline__ LambertRec lambert_record(const De
 		L.colour = first ? v3(ps.lambert[0][0], ps.lambert[0][1], ps.lambert[0][2]) : v3(ps.lambert[1][0], ps.lambert[1][1], ps.lambert[1][2]);
 		L.albedo = first ? ps.lambert[0][3] : ps.lambert[1][3];
 	} else {
-		L.colour = material_texture_colour<F>(S, m, direction, point);
+		L.colour = material_texture_colour<F>(S, m, mat, direction, point);
 		L.albedo = m.param;
 	}
 	return L;
@@ -420,23 +422,23 @@ __device__ inline float tr_pdf(float alpha, V3 incoming, V3 outgoing, V3 normal)
 
 // ---- materials ----
 __device__ __forceinline__ V3 fresnel(float c, V3 f0) { return f0 + (1.0f - f0) * rt_pow5f(1.0f - c); } // refract.rs:59-61
-template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevMaterial &m, const Hit &hit, V3 wo, V3 wi, V3 h) // trowbridge_reitz.rs:26-31
+template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevMaterial &m, uint32_t mat, const Hit &hit, V3 wo, V3 wi, V3 h) // trowbridge_reitz.rs:26-31
 {
 	const V3 ior = v3(m.ior[0], m.ior[1], m.ior[2]);
 	V3 f0 = vabs((1.0f - ior) / (1.0f + ior));
 	f0 = f0 * f0;
-	const V3 tex = material_texture_colour<F>(S, m, wi, hit.point);
+	const V3 tex = material_texture_colour<F>(S, m, mat, wi, hit.point);
 	f0 = (1.0f - m.metallic) * f0 + m.metallic * tex; // lerp :89-91
 	return fresnel(dot(wo, h), f0);
 }
 
-__device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return S.materials[mat].type == 0; }
-template <class F> __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat, int known) { return mat_type_<F>(S.materials[mat], known) == 0; }
+__device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return mat_handle_type(mat) == 0; }
+template <class F> __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat, int known) { return mat_type_<F>(mat, known) == 0; }
 template <class F> __device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
 {
 	if (!F::cmat)
 		return false;
-	const int t = S.materials[mat].type;
+	const int t = mat_handle_type(mat);
 	return t == 3 || t == 4;
 }
 
@@ -453,8 +455,8 @@ template <class F> __device__ __forceinline__ bool reflect_scatter(float fuzz, R
 // Scatter::scatter_ray; returns `exit`
 template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScene &S, uint32_t mat, Ray &ray, const Hit &hit, rt_rng &rng, int known = kMatRead)
 {
-	const DevMaterial &m = S.materials[mat];
-	const int type = mat_type_<F>(m, known);
+	const DevMaterial &m = mat_record(S, mat);
+	const int type = mat_type_<F>(mat, known);
 	if (type == 1) { // Lambertian  lambertian.rs:30-41
 		const V3 direction = lambertian_sample(hit.normal, rng);
 		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
@@ -496,8 +498,8 @@ template <class F> __device__ __forceinline__ bool mat_scatter_ray(const DevScen
 
 template <class F> __device__ __forceinline__ float mat_scattering_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead)
 {
-	const DevMaterial &m = S.materials[mat];
-	const int type = mat_type_<F>(m, known);
+	const DevMaterial &m = mat_record(S, mat);
+	const int type = mat_type_<F>(mat, known);
 	if (type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
 		return fmax_(dot(wi, hit.normal), 0.0f) / kPi;
 	if (F::cmat && type == 2) { // trowbridge_reitz.rs:52-60
@@ -509,8 +511,8 @@ template <class F> __device__ __forceinline__ float mat_scattering_pdf(const Dev
 
 template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead, const DevPairScene &ps = kNoPairScene)
 {
-	const DevMaterial &m = S.materials[mat];
-	const int type = mat_type_<F>(m, known);
+	const DevMaterial &m = mat_record(S, mat);
+	const int type = mat_type_<F>(mat, known);
 	if (type == 1) { // lambertian.rs:45-47
 		const LambertRec L = lambert_record<F>(S, m, mat, wo, hit.point, ps);
 		return L.colour * L.albedo * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
@@ -518,13 +520,13 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 	if (!F::cmat)
 		return v3s(0.0f);
 	if (type == 3 || type == 4) // reflect.rs:36-38, refract.rs:51-53
-		return material_texture_colour<F>(S, m, wo, hit.point);
+		return material_texture_colour<F>(S, m, mat, wo, hit.point);
 	if (type == 2) { // trowbridge_reitz.rs:61-74
 		const V3 wom = -wo;
 		const V3 h = normalised(wi + wom);
 		if (dot(wi, hit.normal) < 0.0f || dot(h, wom) < 0.0f)
 			return v3s(0.0f);
-		const V3 f = tr_fresnel<F>(S, m, hit, wom, wi, h);
+		const V3 f = tr_fresnel<F>(S, m, mat, hit, wom, wi, h);
 		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
 		const float d = tr_d(m.param, dot(hit.normal, h));
 		return f * g * d / (4.0f * fabsf(dot(wom, hit.normal)) * dot(wi, hit.normal));
@@ -534,8 +536,8 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 
 template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo, V3 wi, int known = kMatRead, const DevPairScene &ps = kNoPairScene)
 {
-	const DevMaterial &m = S.materials[mat];
-	const int type = mat_type_<F>(m, known);
+	const DevMaterial &m = mat_record(S, mat);
+	const int type = mat_type_<F>(mat, known);
 	if (type == 1) { // lambertian.rs:48-50
 		const LambertRec L = lambert_record<F>(S, m, mat, wo, hit.point, ps);
 		return L.colour * L.albedo;
@@ -547,7 +549,7 @@ template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScen
 		const V3 h = normalised(wi + wom);
 		if (dot(wom, h) < 0.0f || dot(wi, hit.normal) < 0.0f)
 			return v3s(0.0f);
-		const V3 f = tr_fresnel<F>(S, m, hit, wom, wi, h);
+		const V3 f = tr_fresnel<F>(S, m, mat, hit, wom, wi, h);
 		const float g = tr_g2(m.param, hit.normal, h, wom, wi);
 		return f * g / tr_g1(m.param, hit.normal, h, wom);
 	}
@@ -557,10 +559,10 @@ template <class F> __device__ __forceinline__ V3 mat_eval_over_pdf(const DevScen
 
 template <class F> __device__ __forceinline__ V3 mat_get_emission(const DevScene &S, uint32_t mat, const Hit &hit, V3 wo)
 {
-	const DevMaterial &m = S.materials[mat];
-	if (m.type == 0) { // emissive.rs:23-26
+	const DevMaterial &m = mat_record(S, mat);
+	if (mat_handle_type(mat) == 0) { // emissive.rs:23-26
 		const V3 point = offset_ray(hit.point, hit.normal, hit.err_dot, true);
-		return m.param * material_texture_colour<F>(S, m, wo, point);
+		return m.param * material_texture_colour<F>(S, m, mat, wo, point);
 	}
 	return v3s(0.0f);
 }

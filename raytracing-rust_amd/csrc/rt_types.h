@@ -96,9 +96,24 @@ struct alignas(32) DevLeafBox {
 
 enum : uint32_t { kPrimSphere = 0, kPrimTriangle = 1, kPrimMeshTriangle = 2 };
 
+// Material HANDLE: what a primitive record and DevSky carry and what a path holds on to between bounces --
+//   index << 6 | texture type << 3 | material type
+// The two type tags decide which arm of the shading code runs; read from the record they were the first two links of a
+// chain of dependent loads (type -> texture type -> colours).  Riding in the handle they are known the moment the primitive
+// record (which the hit needs anyway) has arrived, and the one load of the record that remains goes out at once.
+constexpr uint32_t kMatHandleShift = 6u;
+constexpr uint32_t kMatMaxCount = 1u << 24; // meta = prim type (2 bits) | handle << 2
+inline __host__ __device__ uint32_t mat_handle_make(uint32_t index, int32_t type, int32_t tex_type)
+{
+	return (index << kMatHandleShift) | (((uint32_t)tex_type & 7u) << 3) | ((uint32_t)type & 7u);
+}
+inline __host__ __device__ uint32_t mat_handle_index(uint32_t h) { return h >> kMatHandleShift; }
+inline __host__ __device__ int32_t mat_handle_type(uint32_t h) { return (int32_t)(h & 7u); }
+inline __host__ __device__ int32_t mat_handle_tex_type(uint32_t h) { return (int32_t)((h >> 3) & 7u); }
+
 // sphere:   a = (centre.xyz, meta)  b = (radius, 0, 0, 0)   c unused
 // triangle: a = (p0.xyz, meta)      b = (p1.xyz, 0)         c = (p2.xyz, 0)
-// meta = type | material << 2 (bit pattern stored in the float lane)
+// meta = type | material handle << 2 (bit pattern stored in the float lane)
 struct alignas(16) DevPrim {
 	float a[4], b[4], c[4];
 };
@@ -136,7 +151,7 @@ struct DevTexture {
 };
 
 struct DevSky {
-	uint32_t texture, material;
+	uint32_t texture, material; // (material: a handle, see kMatHandleShift)
 	uint32_t res_x, res_y;     // (0,0): not samplable
 	const float *row_cdf;      // res_y * (res_x+1)
 	const float *marginal_cdf; // res_y + 1
