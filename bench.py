@@ -343,16 +343,19 @@ def main():
     cam = hb.camera_new(**camera_params)
 
     opts = workload_opts(abi, name)
-    # A lane folds a whole pixel by default (the reference's sequential running mean), so a GPU cannot
-    # use more lanes than it owns pixels.  One GPU owns 2.07 M pixels for 262 144 resident lanes: fine.
-    # Sharded over N GPUs each owns 1/N of them, so the passes of a pixel are split into S chunks
-    # (rt_render_opts.sample_split: same samples, chunk means combined in fixed order, image moves by
-    # ~1e-7) with S the power of two that keeps >= 32 work items per lane (measured on one GPU's share of
-    # an 8-way sharded frame: 42.9 ms at S = 1, 17.5 ms at S = 64, ideal 15.4 ms).  N = 1 keeps S = 1.
+    # A lane folds one work item at a time; by default an item is a whole pixel (the reference's sequential running mean), so
+    # a GPU cannot use more lanes than it owns pixels, and even one GPU with the whole 1080p frame has only eight items per
+    # resident lane: the last ones run while most of the chip has nothing left (7 % of config 2).  So the passes of a pixel
+    # are split into S chunks (rt_render_opts.sample_split: the same samples, chunk means combined in fixed order, defined
+    # identically in the oracle; the image moves by ~1e-7), S the power of two <= 64 that gives >= 64 work items per resident
+    # lane: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs.  Measured on one GPU: the whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8
+    # share 27.9 ms at S = 1, 11.1 at S = 32 / 64 (an eighth of the whole frame's best: 10.9).  RT_BENCH_SPLIT overrides.
     lanes = 262144
     split = 1
-    while world > 1 and (WIDTH * HEIGHT // world) * split < 32 * lanes and split < SPP // 16:
+    while (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else world)) * split < 64 * lanes and split < 64 and split < SPP // 16:
         split *= 2
+    if os.environ.get("RT_BENCH_SPLIT"):
+        split = int(os.environ["RT_BENCH_SPLIT"])
     opts.sample_split = split
     if abi_devices and len(abi_devices) > 1:
         opts.sample_split = 0  # the library picks the split for its device list (same rule, rt_hip.h)

@@ -258,8 +258,8 @@ void rt_scene_destroy(rt_scene *scene);
  * and write them into the frame there; `rays_shot` is the sum over the devices.  The frame, `d_out_rgb`, `d_rays_shot` and
  * `hip_stream` belong to devices[0].  opts->shard_count must be 1 and the layout RT_LAYOUT_FRAME: the scene shards by itself.
  * opts->sample_split: 1 = every pixel folded strictly in pass order, so the frame equals the single-device frame bit for bit
- * (a device then cannot use more lanes than it owns pixels); 0 = automatic (the power of two that keeps >= 32 work items
- * per resident lane: 1, 16, 32, 64 for 1, 2, 4, 8 GPUs at 1080p); S > 1 as documented at rt_render_opts.  A list of ONE device is
+ * (a device then cannot use more lanes than it owns pixels); 0 = automatic (the power of two <= 64 that gives >= 64 work items
+ * per resident lane: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs at 1080p); S > 1 as documented at rt_render_opts.  A list of ONE device is
  * rt_scene_create.  The same device may be listed more than once (two members then share that GPU).  rt_check_hit[_index]
  * and the introspection calls use devices[0]. ---- */
 int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, rt_scene **out);

@@ -786,12 +786,15 @@ int rt_shard_pixel_order(const rt_render_opts *o, uint64_t *out, uint64_t capaci
 // and one small kernel per shard writes them into the frame.  Nothing synchronises with the host. ----
 static int multi_sample_split(const rt_scene *head, const rt_render_opts *o, uint32_t n)
 {
-	// A lane folds a whole pixel, so a member cannot use more lanes than it owns pixels: split the passes of a pixel into
-	// the power of two of chunks that keeps >= 32 work items per resident lane (measured on one GPU's share of an 8-way
-	// sharded 1080p frame: 42.9 ms at S = 1, 17.5 ms at S = 64, ideal 15.4 ms)
+	// A lane folds one work item at a time and an item is 1 / S of a pixel's passes: with whole pixels (S = 1) a device cannot
+	// use more lanes than it owns pixels, and even one 1080p frame on one GPU is only eight items per resident lane, whose last
+	// ones run while most of the chip has nothing left (7 % of config 2).  The power of two of chunks that gives >= 64 items per
+	// resident lane, at most 64 (a claim of 64 items then stays inside one tile: rt_render.hip acquire_tiles) and at least 16
+	// passes per chunk.  Measured on one GPU, config 2: whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8 share 27.9 ms at
+	// S = 1, 11.1 at S = 32 / 64 (gpurun_out/r05n_split.log).
 	const uint64_t lanes = (uint64_t)head->n_cus * 1024u;
 	uint32_t split = 1;
-	while (n > 1 && (o->width * o->height / n) * split < 32 * lanes && split < o->samples_per_pixel / 16)
+	while ((o->width * o->height / n) * split < 64 * lanes && split < 64u && split < o->samples_per_pixel / 16)
 		split *= 2;
 	return (int)split;
 }
@@ -1000,6 +1003,13 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.tiles_y = g.tiles_y;
 	P.n_work = (uint32_t)g.n_work;
 	const uint32_t split = o->sample_split > 1u ? o->sample_split : 1u;
+	P.tile_log2_w = 0xFFFFFFFFu;
+	if (g.tile_w * g.tile_h == 64u && (g.tile_w & (g.tile_w - 1u)) == 0u && o->width < 65536u && o->height < 65536u &&
+	    (split & (split - 1u)) == 0u && split <= 64u)
+		for (uint32_t lw = 0; lw < 7u; ++lw)
+			for (uint32_t ls = 0; ls < 7u; ++ls)
+				if ((1u << lw) == g.tile_w && (1u << ls) == split)
+					P.tile_log2_w = lw | (ls << 8);
 	if (split > o->samples_per_pixel)
 		return fail(RT_ERR_INVALID_ARGUMENT, "sample_split larger than samples_per_pixel");
 	if (g.n_work * split >= (1ull << 32))

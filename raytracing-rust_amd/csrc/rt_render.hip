@@ -1088,7 +1088,83 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
 #endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
+	// ... and, when a claim lies inside one tile (DevRenderParams::tile_log2_w), that tile's origin (x | y << 16) and the index,
+	// in this shard's pixel order, of the first pixel the claim covers: worked out once per claim, not once per item
+	uint32_t wq_xy = 0, wq_pbase = 0;
+	// Work acquisition when a claim lies inside a tile.  Two things are wrong with decoding every item on its own in chunk-major
+	// order (item = chunk w / n_work of pixel w % n_work, the general path below) once sample_split > 1:
+	//  * the decode -- which tile, which chunk, which passes -- is four 32-bit and two 64-bit integer divisions, some 600
+	//    instructions the whole wave executes whenever ANY of its lanes wants an item;
+	//  * chunk-major order sweeps the image once per chunk, and at the end of every sweep a wave's last lanes are still on the
+	//    expensive pixels at the bottom of the image while the others start on the cheap ones at the top: fewer than
+	//    kLightPhaseThreshold lanes wait for BOUNCE, the others regenerate for ever, and the waiting lanes are stranded until the
+	//    wave reaches expensive pixels again (config 2, stats build: PRIMARY runs with 30 lanes instead of 51; 91 -> 101 ms
+	//    whatever the split).
+	// Here a claim of 64 items is 64 / S consecutive pixels of ONE tile times their S chunks (S a power of two <= 64), the
+	// chunks of a pixel in neighbouring lanes: the image is swept once, like S = 1, the divisions are done once per claim on
+	// wave-uniform values, and a lane's own part is masks and shifts.  What a pixel's chunks return does not depend on who folds
+	// them when, so the frame is the same as under the general order.
+	auto acquire_tiles = [&]() {
+		const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
+		if (need == 0ull)
+			return;
+		const KArgs k = kargs();
+		const uint32_t n = (uint32_t)__popcll(need);
+		const uint32_t avail = wq_end - wq_next;
+		const uint32_t old_next = wq_next, old_xy = wq_xy, old_pbase = wq_pbase;
+		const uint32_t log2_w = k->P.tile_log2_w & 7u, log2_s = k->P.tile_log2_w >> 8, spp = k->P.spp;
+		uint32_t base = wq_end;
+		if (avail < n) { // the range runs short: claim the next 64 items
+			const int leader = __ffsll((long long)need) - 1;
+			uint32_t claimed = 0;
+			if ((int)lane == leader)
+				claimed = atomicAdd(k->work_counter, kClaim);
+			base = (uint32_t)__builtin_amdgcn_readlane((int)claimed, leader);
+			const uint32_t b = base >> 6;              // claim number
+			const uint32_t kt = b >> log2_s;           // ... lies in this shard's kt-th tile
+			const uint32_t sub = b & ((1u << log2_s) - 1u); // ... and is that tile's sub-th group of 64 / S pixels
+			const uint32_t tile = k->P.shard_index + kt * k->P.shard_count;
+			const uint32_t ty = tile / k->P.tiles_x;
+			const uint32_t tx = tile - ty * k->P.tiles_x;
+			wq_xy = (tx << log2_w) | ((ty * k->P.tile_h) << 16);
+			wq_pbase = (kt << 6) + (sub << (6u - log2_s));
+		}
+		if (ph == PH_NEED_PIXEL) {
+			const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+			const bool from_old = r < avail;
+			const uint32_t w = from_old ? old_next + r : base + (r - avail);
+			const uint32_t xy = from_old ? old_xy : wq_xy;
+			const uint32_t in = w & 63u;
+			const uint32_t wp = (from_old ? old_pbase : wq_pbase) + (in >> log2_s); // the pixel, in this shard's order
+			const uint32_t c = in & ((1u << log2_s) - 1u);                            // ... and which of its chunks
+			const uint32_t in_tile = wp & 63u;
+			px = (xy & 0xFFFFu) + (in_tile & ((1u << log2_w) - 1u));
+			py = (xy >> 16) + (in_tile >> log2_w);
+			if (w >= k->P.n_items) {
+				ph = PH_DONE;
+			} else if (px < k->P.width && py < k->P.height) {
+				pixel_index = py * k->P.width + px;
+				chunk_begin = (uint32_t)(((uint64_t)c * spp) >> log2_s); // = c * spp / S (rt_hip.h sample_split)
+				chunk_n = (uint32_t)(((uint64_t)(c + 1u) * spp) >> log2_s) - chunk_begin;
+				// chunk means go to the partial buffer chunk-major (combine_chunks_kernel); whole pixels to the frame or the packed shard
+				out_index = log2_s != 0u ? c * k->P.n_work + wp : (k->P.shard_layout ? wp : pixel_index);
+				sample_local = 0;
+				mean = v3s(0.0f);
+				ph = PH_GEN;
+			} // else: padding of an edge tile; ask again next iteration
+		}
+		if (avail < n) { // the leftovers went first, the rest came from the new claim
+			wq_next = base + (n - avail);
+			wq_end = base + kClaim;
+		} else {
+			wq_next += n;
+		}
+	};
 	auto acquire = [&]() {
+	if (!FINE && P.tile_log2_w != 0xFFFFFFFFu) { // (wave-uniform; the fine kernels measured 1.5 % slower with it on 1 M triangles, r05p)
+		acquire_tiles();
+		return;
+	}
 	// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
 	// work items [wq_next, wq_end); when that runs short the wave claims kClaim more items with ONE
 	// atomic on the global counter (a single word sustains only ~88 dequeues/us on this chip, and

@@ -237,6 +237,11 @@ struct DevRenderParams {
 	uint32_t stack_cap;       // traversal stack entries per lane kept in LDS (rt_intersect.h StackMem)
 	uint32_t stack_ovf_depth; // ... and in the global overflow area (0: the LDS part covers the worst case)
 	uint32_t xchg_slots;      // RT_TUNE_EXCHANGE: parked paths / pixels the workgroup's pool holds (rt_render.hip, XCHG)
+	// Tiles of exactly 64 pixels with a power-of-two width (the default 8 x 8) on an image below 65 536 x 65 536 and a
+	// sample_split that is a power of two <= 64: log2 of the tile width | log2 of the split << 8.  A wave's claim of 64 work
+	// items then lies inside ONE tile -- 64 / S of its pixels times their S chunks -- whose origin is worked out once per claim
+	// (rt_render.hip, acquire_tiles).  0xFFFFFFFF: any other tiling or split, every item is decoded on its own (chunk-major).
+	uint32_t tile_log2_w;
 };
 
 } // namespace rt
