@@ -145,6 +145,8 @@ template <class F, bool FINE = false, bool XCHG = false> struct KernelShape {
 #ifdef RT_STATS
 // diagnostic build only: schedule statistics, read back with hipMemcpyFromSymbol by tests/probes/gpu_stats_probe.py
 __device__ unsigned long long g_stats[64];
+__device__ unsigned long long g_hist[4][65]; // coarse schedule, by lane count: [0] PRIMARY iterations by participating lanes, [1] by
+                                             // lanes waiting for BOUNCE at that moment, [2] acquire events by needy lanes, [3] BOUNCE iterations
 #endif
 
 // Cross-wave exchange of path state (XCHG, coarse MIS kernels, opt-in through RT_TUNE_EXCHANGE): a lane whose path
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	};
 
 #ifdef RT_STATS
-	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0;
+	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0, st_hist[8] = {};
 	unsigned long long st_sect[9] = {}, st_mark = wall_clock64();
 	unsigned long long st_fine_clock[PH_COUNT + 1] = {};
 	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
@@ -1110,6 +1112,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			return;
 		const KArgs k = kargs();
 		const uint32_t n = (uint32_t)__popcll(need);
+#ifdef RT_STATS
+		if (lane == 0u)
+			atomicAdd(&g_hist[2][n], 1ull);
+#endif
 		const uint32_t avail = wq_end - wq_next;
 		const uint32_t old_next = wq_next, old_xy = wq_xy, old_pbase = wq_pbase;
 		const uint32_t log2_w = k->P.tile_log2_w & 7u, log2_s = k->P.tile_log2_w >> 8, spp = k->P.spp;
@@ -1135,6 +1141,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			const uint32_t w = from_old ? old_next + r : base + (r - avail);
 			const uint32_t xy = from_old ? old_xy : wq_xy;
 			const uint32_t in = w & 63u;
+			// (the other single-sweep layout -- a claim = all 64 pixels of the tile for ONE chunk, claims tile-major -- measured the
+			// same to 0.3 % at every split: gpurun_out/r05v)
 			const uint32_t wp = (from_old ? old_pbase : wq_pbase) + (in >> log2_s); // the pixel, in this shard's order
 			const uint32_t c = in & ((1u << log2_s) - 1u);                            // ... and which of its chunks
 			const uint32_t in_tile = wp & 63u;
@@ -1344,9 +1352,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				if (lane == 0u) {
 					if (!run_light) {
 						st_iters[0] += 1; st_active[0] += n_trace;
+						st_hist[(n_trace - 1u) >> 3] += 1; // PRIMARY iterations by the lanes that take part, in eighths of a wave
+						atomicAdd(&g_hist[0][n_trace], 1ull);
+						atomicAdd(&g_hist[1][n_light], 1ull);
 						st_gen += (unsigned long long)__popcll(__ballot(ph == PH_GEN));
 					} else {
 						st_iters[1] += 1; st_active[1] += n_light;
+						atomicAdd(&g_hist[3][n_light], 1ull);
 					}
 				}
 	#endif
@@ -1463,6 +1475,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	if (lane == 0u) {
 		for (int k = 0; k < 9; ++k)
 			atomicAdd(&g_stats[40 + k], st_sect[k]);
+		for (int k = 0; k < 8; ++k)
+			atomicAdd(&g_stats[24 + k], st_hist[k]);
 		for (int k = 0; k <= PH_COUNT; ++k)
 			atomicAdd(&g_stats[50 + k], st_fine_clock[k]);
 		atomicAdd(&g_stats[0], st_iters[0]); atomicAdd(&g_stats[1], st_active[0]);
@@ -1941,6 +1955,16 @@ hipError_t launch_selftest_lean(hipStream_t stream, uint32_t blocks, uint64_t n_
 
 // ---- launchers (called from rt_api.cpp) ----
 #ifdef RT_STATS
+extern "C" int rt_debug_hist(unsigned long long *out260, int reset)
+{
+	if (hipMemcpyFromSymbol(out260, HIP_SYMBOL(g_hist), sizeof(g_hist)) != hipSuccess)
+		return -1;
+	if (reset) {
+		unsigned long long z[4 * 65] = {};
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z, sizeof z);
+	}
+	return 0;
+}
 extern "C" int rt_debug_stats(unsigned long long *out16, int reset)
 {
 	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stats), sizeof(g_stats)) != hipSuccess)

@@ -19,6 +19,8 @@ for name in ("rtweekend1", "overshadowed"):
     tot = max(1, sum(sect))
     names = ["vote+claim", "P:gen", "P:walk", "P:shade", "Q:light", "Q:shadow walk", "Q:scatter", "Q:walk", "Q:shade"]
     print("   wave wall-clock share: " + "  ".join(f"{nm} {100*v/tot:.1f}%" for nm, v in zip(names, sect)))
+    hist = [out[24 + k] for k in range(8)]
+    print("   PRIMARY iterations by participating lanes (1-8, 9-16, ... 57-64): " + "  ".join(f"{100*v/max(1,sum(hist)):.1f}%" for v in hist))
     n = 1920 * 1080 * int(o.samples_per_pixel)
     print(f"{name}: TRACE iters {ti} avg active {ta/ti:.1f}/64 (gen lanes/iter {gen/ti:.1f}) | LIGHT iters {li} avg active {la/li:.1f}/64 | "
           f"per sample: trace-lane-steps {ta/n:.2f} light-lane-steps {la/n:.2f}; wave-iters per 64 samples: trace {ti*64/n:.2f} light {li*64/n:.2f}")
