@@ -182,14 +182,16 @@ typedef struct rt_render_opts {
 	uint32_t tile_width;    /* shard granularity in pixels; 0 = default (8) */
 	uint32_t tile_height;   /* 0 = default (8) */
 	int32_t output_layout;  /* rt_output_layout */
-	/* 1 (default; 0 means the same on a single-device scene and "automatic" on a multi-device one, rt_scene_create_multi):
-	 * a pixel's passes are folded strictly in pass order, `mean += (pass-mean)/i`,
-	 * the reference's accumulation (src/main.rs:179-185).  S > 1: the passes of a pixel are split
+	/* 1 (default): a pixel's passes are folded strictly in pass order, `mean += (pass-mean)/i`,
+	 * the reference's accumulation (src/main.rs:179-185).  0 = automatic: the power of two <= 64 that gives this device
+	 * >= 64 work items per resident lane (16 for one GPU at 1080p; rt_last_launch_info reports the choice).
+	 * S > 1: the passes of a pixel are split
 	 * into S contiguous chunks [floor(c*spp/S), floor((c+1)*spp/S)) that are folded independently
 	 * (each with its own i = 1..n_c) and combined in chunk order as
 	 * (sum_c mean_c * n_c) / spp in f32.  Same samples, same streams, a different summation order:
-	 * the image changes at the 1e-7 level.  It exists for parallelism: without it a render cannot use
-	 * more lanes than it has pixels (8 GPUs at 1080p have one pixel per lane). */
+	 * the image changes at the 1e-7 level.  It exists for parallelism and for balance: without it a render cannot use
+	 * more lanes than it has pixels (8 GPUs at 1080p have one pixel per lane), and even one GPU ends a 1080p frame with
+	 * most of its lanes idle while the last whole pixels finish (7 - 29 % of the launch on the BASELINE workloads). */
 	uint32_t sample_split;
 	uint32_t reserved0;
 } rt_render_opts;

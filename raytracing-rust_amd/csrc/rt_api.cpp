@@ -1002,7 +1002,13 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.tiles_x = g.tiles_x;
 	P.tiles_y = g.tiles_y;
 	P.n_work = (uint32_t)g.n_work;
-	const uint32_t split = o->sample_split > 1u ? o->sample_split : 1u;
+	// sample_split 0 = automatic, on one device as on several (multi_sample_split: >= 64 work items per resident lane)
+	uint32_t split = o->sample_split;
+	if (split == 0u) {
+		split = (uint32_t)multi_sample_split(s, o, o->shard_count ? o->shard_count : 1u);
+		if (split > o->samples_per_pixel)
+			split = (uint32_t)o->samples_per_pixel;
+	}
 	P.tile_log2_w = 0xFFFFFFFFu;
 	if (g.tile_w * g.tile_h == 64u && (g.tile_w & (g.tile_w - 1u)) == 0u && o->width < 65536u && o->height < 65536u &&
 	    (split & (split - 1u)) == 0u && split <= 64u)
