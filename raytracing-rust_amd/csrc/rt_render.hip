@@ -62,6 +62,16 @@ enum : int {
 #define RT_LIGHT_PHASE_THRESHOLD 48
 #endif
 constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
+// ... or, short of that many, once the paths that wait for it have waited this many lane-iterations between them.  The lane
+// threshold alone strands them in a wave whose other lanes only ever regenerate: a wave that holds a few cheap (sky) items next to
+// expensive ones never collects 48 waiting lanes, and the waiting ones sit idle until the cheap items run out.  Whole-pixel items
+// hid this (a wave then takes a tile at a time); with sample_split a wave whose lanes finish at different times pulls a block of
+// cheap items and hands them to a few lanes at a time (stats build, config 2 at S = 16: 37 % of PRIMARY iterations ran with
+// 17 - 24 lanes while 40 - 47 waited).  0 = off.
+#ifndef RT_STARVE_LIMIT
+#define RT_STARVE_LIMIT 128 // config 2 at S = 16, same box: off 87.0 ms, 48 / 96 / 192 / 384 -> 80.6 / 80.0 / 79.8 / 80.1 (gpurun_out/r05w); at S = 1 within noise
+#endif
+constexpr uint32_t kStarveLimit = RT_STARVE_LIMIT;
 constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
 #ifndef RT_DRAIN_LANES
 #define RT_DRAIN_LANES 6
@@ -1336,6 +1346,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	// structurised loop copied the whole loop-carried lane state -- about 45 registers -- twice per iteration.) ----
 	if constexpr (!FINE) {
 		bool alive = true; // wave-uniform
+		// lane-iterations that paths have spent waiting for BOUNCE since it last ran (wave-uniform; see kStarveLimit)
+		uint32_t waited = 0;
 		while (alive) {
 			if (XCHG && METHOD == 1)
 				exchange();
@@ -1347,7 +1359,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			const uint32_t n_light = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
 			const uint32_t n_trace = (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
 			if (n_light + n_trace != 0u) {
-				const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u);
+				const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u || (kStarveLimit != 0u && waited >= kStarveLimit));
+				waited = run_light ? 0u : waited + n_light;
 	#ifdef RT_STATS
 				if (lane == 0u) {
 					if (!run_light) {
@@ -1384,6 +1397,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 						// top of the next iteration would choose, without the trip round the loop in between
 						const uint32_t n_light_now = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
 						run_q = n_light_now >= kLightPhaseThreshold;
+						if (run_q)
+							waited = 0u;
 	#ifdef RT_STATS
 						if (run_q && lane == 0u) {
 							st_iters[1] += 1; st_active[1] += n_light_now;
