@@ -2,7 +2,7 @@
 rank 0's 1/8 tile shard in one render (about 80 s of GPU), with the CPU oracle rendering six of that shard's tiles at the same
 depth and the pixels compared bit for bit; and SURVEY 8(d)'s algorithmic bytes per sample for this workload, counted by the
 oracle under reference traversal semantics on a sparse tile subset.  Writes gpurun_out/<tag>_mesh10m_full.json.
-    python tests/probes/gpu_mesh10m_full.py <tag> [spp]"""
+    python tests/probes/gpu_mesh10m_full.py <tag> [spp] [sample_split]     (the oracle renders its tiles at the same split)"""
 import importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,7 @@ import oracle as O
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+split = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 name = "mesh10m"
 w = bench.WORKLOADS[name]
 t0 = time.time()
@@ -25,6 +26,7 @@ print(f"product: BVH + upload {time.time() - t0:.1f} s", flush=True)
 cam = hb.camera_new(**cam_params)
 opts = bench.workload_opts(abi, name, spp)          # shard 0 of 8, frame layout
 opts.output_layout = abi.RT_LAYOUT_SHARD
+opts.sample_split = split
 t0 = time.time()
 shard, rays = g.render(cam, opts)
 wall = time.time() - t0
@@ -42,6 +44,7 @@ tiles_owned = (w["width"] // 8) * (w["height"] // 8) // 8
 m = tiles_owned // 6
 sub = bench.workload_opts(abi, name, spp)
 sub.shard_index, sub.shard_count = 0, 8 * m
+sub.sample_split = split
 t0 = time.time()
 ref, ref_rays = c.render(ocam, sub, n_threads=os.cpu_count())   # the oracle writes its shard's pixels into a whole frame
 t_or = time.time() - t0
@@ -63,7 +66,7 @@ n_cnt = (w["width"] * w["height"] // (8 * 512)) * 2
 per = {k: v / n_cnt for k, v in counters.items()}
 alg = 32 * per["node_tests"] + 36 * per["triangle_tests"] + 16 * per["sphere_tests"] + 52 * per["closest_hits"] + 64 * per["sky_ops"] + 12.0 / w["full_spp"]
 print(f"oracle counters on {n_cnt} samples in {time.time() - t0:.1f} s: {alg:.0f} algorithmic bytes per sample", flush=True)
-out = {"workload": "mesh10m: 10 M triangles, 4096x4096, shard 0 of 8 (BASELINE configs[4], one rank)", "spp": spp, "samples": n_samples,
+out = {"workload": "mesh10m: 10 M triangles, 4096x4096, shard 0 of 8 (BASELINE configs[4], one rank)", "spp": spp, "sample_split": split, "samples": n_samples,
        "kernel_s": kernel_ms / 1e3, "wall_s_rt_render": wall, "Msamples_per_s": n_samples / kernel_ms / 1e3, "rays_shot": int(rays),
        "oracle_check": {"tiles": n_tiles, "passes": spp, "pixels_identical": same, "oracle_seconds": t_or, "threads": os.cpu_count()},
        "survey_8d_algorithmic": {"bytes_per_sample": alg, "per_sample": per, "counted_on": f"every 512th tile of the shard x 2 passes ({n_cnt} samples)",
