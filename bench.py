@@ -350,9 +350,12 @@ def main():
     # identically in the oracle; the image moves by ~1e-7), S the power of two <= 64 that gives >= 64 work items per resident
     # lane: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs.  Measured on one GPU: the whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8
     # share 27.9 ms at S = 1, 11.1 at S = 32 / 64 (an eighth of the whole frame's best: 10.9).  RT_BENCH_SPLIT overrides.
+    # A chunk is at least 16 passes on one GPU and 4 when the frame is sharded over several (a rank's share of config 4 at 8 GPUs is
+    # 256 passes of 259 k pixels: 146 / 140 / 135 ms at S = 16 / 32 / 64 on one GPU's share, ideal 124: profiles/r03k_mesh1m_share*.txt).
     lanes = 262144
     split = 1
-    while (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else world)) * split < 64 * lanes and split < 64 and split < SPP // 16:
+    min_chunk = 16 if world == 1 else 4
+    while (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else world)) * split < 64 * lanes and split < 64 and split < SPP // min_chunk:
         split *= 2
     if os.environ.get("RT_BENCH_SPLIT"):
         split = int(os.environ["RT_BENCH_SPLIT"])
