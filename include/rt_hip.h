@@ -288,6 +288,13 @@ int rt_scene_get_wide_nodes(const rt_scene *scene, void *out, uint64_t capacity_
 /* exact leaf boxes of the wide walk, one { float lo[3], pad, hi[3], pad } per primitive slot (meaningful at the first
  * slot of every leaf) */
 int rt_scene_get_leaf_boxes(const rt_scene *scene, float *out, uint64_t capacity_slots);
+/* ... and the COMPACT form itself, byte for byte what the kernels fetch (csrc/rt_types.h DevNodeQ4): n_wide_nodes 64-byte records
+ * of the same layout with  child[0] = first inner child | leaf mask << 26,  child[1] = first leaf index | present mask << 26,
+ * the 2-bit per-child offsets in the top byte of `exps`; and the exact leaf boxes BY LEAF INDEX, { lo[3], ref, hi[3], pad } with
+ * ref = the leaf's own reference (bit pattern).  *n_leaves receives the leaf count (may be asked for with out = NULL).
+ * tests/test_host_bvh.py walks this form in numpy the way rt_intersect.h descend4 does. */
+int rt_scene_get_wide_nodes_compact(const rt_scene *scene, void *out, uint64_t capacity_nodes);
+int rt_scene_get_leaf_boxes_compact(const rt_scene *scene, float *out, uint64_t capacity_leaves, uint64_t *n_leaves);
 
 /* How the BVH is walked: -1 automatic (default), 0 exhaustive = every AABB-hit node and every
  * primitive of every hit leaf, the reference's own amount of work (acceleration/mod.rs:199-224,

@@ -238,6 +238,8 @@ EXPORTED_SYMBOLS = [
     "rt_scene_wide_info",
     "rt_scene_get_wide_nodes",
     "rt_scene_get_leaf_boxes",
+    "rt_scene_get_wide_nodes_compact",
+    "rt_scene_get_leaf_boxes_compact",
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",
     "rt_render",

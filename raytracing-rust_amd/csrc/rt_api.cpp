@@ -668,6 +668,26 @@ int rt_scene_get_leaf_boxes(const rt_scene *s, float *out, uint64_t capacity_slo
 	std::memcpy(out, s->host.leaf_box.data(), s->host.leaf_box.size() * sizeof(DevLeafBox));
 	return RT_OK;
 }
+int rt_scene_get_wide_nodes_compact(const rt_scene *s, void *out, uint64_t capacity_nodes)
+{
+	if (!s || !out || capacity_nodes < s->host.dev_nodes4c.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.dev_nodes4c.data(), s->host.dev_nodes4c.size() * sizeof(DevNodeQ4));
+	return RT_OK;
+}
+int rt_scene_get_leaf_boxes_compact(const rt_scene *s, float *out, uint64_t capacity_leaves, uint64_t *n_leaves)
+{
+	if (!s)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null scene");
+	if (n_leaves)
+		*n_leaves = s->host.leaf_box_c.size();
+	if (!out)
+		return n_leaves ? RT_OK : fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	if (capacity_leaves < s->host.leaf_box_c.size())
+		return fail(RT_ERR_INVALID_ARGUMENT, "bad arguments");
+	std::memcpy(out, s->host.leaf_box_c.data(), s->host.leaf_box_c.size() * sizeof(DevLeafBox));
+	return RT_OK;
+}
 int rt_scene_get_lights(const rt_scene *s, uint64_t *out, uint64_t capacity)
 {
 	if (!s || !out || capacity < s->host.lights.size())

@@ -780,12 +780,14 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 			for (size_t w = 0; w < hs.dev_nodes4.size() && ok; ++w) {
 				const DevNodeQ4 &src = hs.dev_nodes4[w];
 				DevNodeQ4 dn = src;
-				uint32_t inner_base = 0, n_inner = 0, n_leaf = 0, leaf_mask = 0, deltas = 0;
+				uint32_t inner_base = 0, n_inner = 0, n_leaf = 0, leaf_mask = 0, deltas = 0, present = 0;
 				const uint32_t leaf_base = (uint32_t)hs.leaf_box_c.size();
 				for (int k = 0; k < 4; ++k) {
 					const uint32_t c = src.child[k];
 					if (c == kRefNone)
-						continue; // (its stored interval is inverted on every axis: the walk's box test rejects it by itself)
+						continue; // (its stored interval is inverted on every axis AND its bit of the present mask stays clear: the
+						          // padded box test alone lets an inverted interval through once the node is small and far away)
+					present |= 1u << k;
 					if (c & kLeafFlag) {
 						uint32_t first = c & kLeafSlotMask;
 						if (((c >> 26) & 31u) == 0u)
@@ -807,13 +809,21 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 				ok = ok && inner_base < (1u << 26) && leaf_base + n_leaf < (1u << 26);
 				dn.exps = (src.exps & 0x00FFFFFFu) | (deltas << 24);
 				dn.child[0] = inner_base | (leaf_mask << 26);
-				dn.child[1] = leaf_base;
+				dn.child[1] = leaf_base | (present << 26);
 				dn.child[2] = dn.child[3] = 0u; // (never fetched)
 				hs.dev_nodes4c[w] = dn;
-				for (int k = 0; k < 4 && ok; ++k) { // decode as the kernel does (rt_intersect.h wide_child_ref) and compare
+				// the walk looks up the present bits of slots 2 and 3 only: a collapsed reference node has its two children at least,
+				// and absent children are the trailing ones
+				ok = ok && (present == 0x3u || present == 0x7u || present == 0xFu);
+				for (int k = 0; k < 4 && ok; ++k) { // decode as the kernel does (rt_intersect.h descend4: ref_of, present bits) and compare
 					const uint32_t c = src.child[k];
-					if (c == kRefNone)
+					const bool is_present = ((dn.child[1] >> (26 + k)) & 1u) != 0u;
+					ok = ok && is_present == (c != kRefNone);
+					if (c == kRefNone) { // absent: never visited, and its interval stays inverted on every axis all the same
+						for (int a = 0; a < 3; ++a)
+							ok = ok && ((dn.qlo[a] >> (8 * k)) & 255u) == 255u && ((dn.qhi[a] >> (8 * k)) & 255u) == 0u;
 						continue;
+					}
 					const uint32_t delta = (dn.exps >> (24 + 2 * k)) & 3u;
 					const bool is_leaf = ((dn.child[0] >> (26 + k)) & 1u) != 0u;
 					if (is_leaf) {

@@ -526,7 +526,14 @@ __device__ __forceinline__ uint32_t descend4(const DevScene &S, const StackMem &
 		const float tf = fminf(fminf(fmaf((float)((fx >> sh) & 0xFFu), ax, bx), fmaf((float)((fy >> sh) & 0xFFu), ay, by)),
 		                       fmaf((float)((fz >> sh) & 0xFFu), az, bz));
 		const float te = fmaxf(tn - pad, 0.0f);
-		const bool h = (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut); // (an absent child's interval is inverted: tf - tn = -255 |a|)
+		bool h = (tf - tn >= -2.0f * pad) && (tf >= -pad) && (te - kPruneSlack * te <= cut);
+		// An ABSENT child needs its own bit.  Its stored interval is inverted on every axis (tf - tn <= -255 max|a|), but the pad
+		// grows with the node's distance: once the node's extent falls below ~2e-5 of it (a small, finely tessellated object far
+		// away; a node of coincident primitives at any distance) the inverted interval passes the padded test, ref_of decodes a
+		// phantom child and the walk re-enters a node it has been to.  Children 0 and 1 always exist (a wide node is a collapsed
+		// reference node: two children at least; the host checks it), so only slots 2 and 3 are looked up: bits 28, 29 of q2.w.
+		if (c >= 2)
+			h = h && ((q2.w >> (26u + (uint32_t)c)) & 1u) != 0u;
 		key[c] = h ? ((__float_as_uint(te) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
 	}
 #define RT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); key[b] = max(key[a], key[b]); key[a] = lo_; }

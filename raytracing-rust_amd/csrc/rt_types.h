@@ -70,12 +70,13 @@ static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 // Absent children have child == kRefNone.
 // COMPACT FORM (what the kernels fetch; rt_build.cpp encodes it from the explicit form above and decodes every node back as a
 // check): the inner children of a node are consecutive nodes and its leaf children consecutive LEAF INDICES, so the four
-// references fold into   child[0] = first inner child | leaf mask << 26   child[1] = first leaf index
+// references fold into   child[0] = first inner child | leaf mask << 26   child[1] = first leaf index | present mask << 26
 // and a 2-bit offset per child in the top byte of `exps` (child k is inner node child[0] + offset_k or leaf child[1] +
 // offset_k by bit k of the mask).  A node step then needs only the first THREE 16-byte pieces of the record -- the walk
 // is bound by the number of such pieces its lanes fetch -- and a leaf's (first slot, count) reference
 // rides in the spare word of its exact box (DevLeafBox::ref), which the walk fetches anyway before it touches a primitive.
-// An absent child needs no flag: its stored interval is inverted on every axis, so the walk's own box test rejects it.
+// An absent child has its bit of the present mask clear (and an inverted interval on every axis: but the walk's padded box
+// test lets an inverted interval through once the node's extent is below ~2e-5 of its distance, so the bit is what counts).
 constexpr uint32_t kRefNone = 0x7FFFFFFEu;
 struct alignas(64) DevNodeQ4 {
 	float origin[3];     // lower corner of the node's grid

@@ -168,6 +168,19 @@ class HipScene:
             _check(lib().rt_scene_get_leaf_boxes(self._h, _p(boxes, C.c_float), C.c_uint64(boxes.shape[0])))
         return nodes[:n.value], root.value, depth.value, boxes
 
+    def wide_tree_compact(self):
+        """(compact wide nodes -- the bytes the kernels fetch --, leaf boxes by leaf index [n_leaves, 8])"""
+        n, root, depth = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _check(lib().rt_scene_wide_info(self._h, C.byref(n), C.byref(root), C.byref(depth)))
+        nodes = np.zeros(max(1, n.value), dtype=WIDE_NODE_DTYPE)
+        n_leaves = C.c_uint64()
+        _check(lib().rt_scene_get_leaf_boxes_compact(self._h, None, C.c_uint64(0), C.byref(n_leaves)))
+        boxes = np.zeros((max(1, n_leaves.value), 8), dtype=np.float32)
+        if n.value:
+            _check(lib().rt_scene_get_wide_nodes_compact(self._h, nodes.ctypes.data_as(C.c_void_p), C.c_uint64(n.value)))
+            _check(lib().rt_scene_get_leaf_boxes_compact(self._h, _p(boxes, C.c_float), C.c_uint64(boxes.shape[0]), C.byref(n_leaves)))
+        return nodes[:n.value], boxes[:n_leaves.value]
+
     def set_traversal(self, mode):
         """-1 auto, 0 exhaustive (reference amount of work), 1 pruned."""
         _check(lib().rt_scene_set_traversal(self._h, C.c_int(mode)))

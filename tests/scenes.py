@@ -280,3 +280,33 @@ def floor_under(light=None, sky=None, sampler_res=(0, 0), rho=(0.8, 0.6, 0.4), a
     else:
         sc.set_sky(sc.solid((0.0, 0.0, 0.0)), sampler_res)
     return sc
+
+
+def small_far_scenes():
+    """[(name, scene, point to aim at)]: wide nodes with ABSENT children whose extent is far below 2e-5 of the distance rays
+    come from -- where the padded interval test of the wide walk (rt_intersect.h descend4) lets an absent child's inverted
+    interval through, so only the node's present mask keeps the walk out of it."""
+    out = []
+    # three tiny spheres in a clump: one all-leaf root node of extent 4e-5 (a phantom child decodes to node 0, the root itself).
+    # (Centroids closer than 100 * f32::EPSILON = 1.2e-5 on the widest axis would make ONE leaf: acceleration/mod.rs:129-134.)
+    sc = SceneDescription()
+    m = sc.lambertian(sc.solid(0.5), 0.5)
+    for k in range(3):
+        sc.sphere((2.0e-5 * k, 1.0e-5 * (k % 2), -1.5e-5 * k), 5.0e-6, m)
+    sc.set_sky(sc.solid(1.0), (0, 0))
+    out.append(("three tiny spheres", sc, np.zeros(3, np.float32)))
+    # a floor, a few ordinary spheres and, far from everything, a clump of three small triangles: a 3-child node deep in the tree
+    sc = SceneDescription()
+    m = sc.lambertian(sc.solid(0.5), 0.5)
+    sc.sphere((0.0, 0.0, -1000.0), 999.0, m)
+    rng = np.random.default_rng(4)
+    for k in range(12):
+        sc.sphere(tuple(rng.uniform(-3, 3, 3)), 0.4, m)
+    c = np.array([40.0, 35.0, 30.0])
+    up = [(0.0, 0.0, 1.0)] * 3
+    for k in range(3):
+        p = c + np.array([1.0e-4 * k, 0.0, 0.0]) + rng.uniform(-1, 1, 3) * 2.0e-5
+        sc.triangle([tuple(p), tuple(p + np.array([3.0e-5, 0, 0])), tuple(p + np.array([0, 3.0e-5, 1.0e-5]))], up, m)
+    sc.set_sky(sc.solid(1.0), (0, 0))
+    out.append(("a far clump of triangles", sc, c.astype(np.float32)))
+    return out

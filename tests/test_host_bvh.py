@@ -215,3 +215,103 @@ def test_wide_tree_sizes_and_degenerate_boxes(hb):
         sc.sphere((bad, 0.0, 0.0), 1.0, m)
         sc.set_sky(sc.solid(0.5), (0, 0))
         assert len(hb.HipScene(sc, device=abi.RT_DEVICE_NONE).wide_tree()[0]) == 0
+
+
+# ---- the COMPACT wide node (what the kernels fetch) and its absent children.  rt_intersect.h descend4 accepts a child when its
+# padded interval test passes; an absent child's interval is inverted (qlo = 255, qhi = 0 on every axis), which the test rejects
+# only while 255 * max|a| > 2 * pad, pad = 1e-5 * (max|b| + 255 * max|a|): a node whose extent is below ~2e-5 of its distance lets
+# the phantom through.  Decoded, a phantom child of an all-leaf node is wide node 0 -- the root: the walk would never end.  So the
+# node carries a present mask (bits 26-29 of child[1]) and the walk looks slots 2 and 3 up in it.  This walks the compact bytes in
+# numpy f32 the way descend4 does: with the mask, every walk ends and reaches no absent child; WITHOUT it the scenes below do
+# produce phantoms (the hazard is real, the test would have caught it). ----
+def _f32(x):
+    return np.float32(x)
+
+
+def _fma(a, b, c):
+    return np.float32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def _descend4_children(node, o, inv, use_present_mask):
+    """child slots descend4 would visit (nearest first), emulated in f32; no pruning (limit_valid = false)"""
+    exps = int(node["exps"])
+    s = [np.uint32(((exps >> (8 * a)) & 0xFF) << 23).view(np.float32) for a in range(3)]
+    a_ = [_f32(s[k] * inv[k]) for k in range(3)]
+    b_ = [_f32(_f32(node["origin"][k] - o[k]) * inv[k]) for k in range(3)]
+    near = [int(node["qhi"][k]) if inv[k] < 0 else int(node["qlo"][k]) for k in range(3)]
+    far = [int(node["qlo"][k]) if inv[k] < 0 else int(node["qhi"][k]) for k in range(3)]
+    big = _f32(max(abs(b_[0]), abs(b_[1]), abs(b_[2])) + _f32(255.0) * max(abs(a_[0]), abs(a_[1]), abs(a_[2])))
+    pad = _f32(_f32(1.0e-5) * big)
+    present = int(node["child"][1]) >> 26
+    out = []
+    for c in range(4):
+        tn = max(_fma(_f32((near[k] >> (8 * c)) & 0xFF), a_[k], b_[k]) for k in range(3))
+        tf = min(_fma(_f32((far[k] >> (8 * c)) & 0xFF), a_[k], b_[k]) for k in range(3))
+        te = max(_f32(tn - pad), _f32(0.0))
+        h = (_f32(tf - tn) >= _f32(-2.0) * pad) and (tf >= -pad)
+        if use_present_mask and c >= 2:
+            h = h and ((present >> c) & 1) != 0
+        if h:
+            out.append((float(te), c))
+    return [c for _, c in sorted(out)]
+
+
+def _compact_ref(node, c):
+    delta = (int(node["exps"]) >> (24 + 2 * c)) & 3
+    if (int(node["child"][0]) >> (26 + c)) & 1:
+        return LEAF | ((int(node["child"][1]) & 0x03FFFFFF) + delta)
+    return (int(node["child"][0]) & 0x03FFFFFF) + delta
+
+
+def _walk_compact(nodes, root, o, d, use_present_mask, max_steps):
+    """(leaf indices reached, absent slots visited, node steps); gives up after max_steps node steps"""
+    with np.errstate(all="ignore"):
+        d = (d / np.sqrt((d * d).sum(dtype=np.float32))).astype(np.float32)
+        inv = (np.float32(1.0) / d).astype(np.float32)
+        stack, leaves, phantoms, steps = [root], [], 0, 0
+        while stack and steps < max_steps:
+            ref = stack.pop()
+            if ref & LEAF:
+                leaves.append(ref & 0x03FFFFFF)
+                continue
+            steps += 1
+            node = nodes[ref]
+            kids = _descend4_children(node, o, inv, use_present_mask)
+            present = int(node["child"][1]) >> 26
+            phantoms += sum(1 for c in kids if not (present >> c) & 1)
+            for c in reversed(kids):
+                stack.append(_compact_ref(node, c))
+    return leaves, phantoms, steps
+
+
+def test_compact_wide_walk_never_visits_an_absent_child(hb):
+    rng = np.random.default_rng(8)
+    hazard_seen = False
+    for what, sc, target in scenes.small_far_scenes():
+        g = hb.HipScene(sc, device=abi.RT_DEVICE_NONE)
+        nodes, leaf_boxes = g.wide_tree_compact()
+        explicit, root, depth, _ = g.wide_tree()
+        assert len(nodes) == len(explicit) and len(nodes) >= 1, what
+        for w in range(len(nodes)):  # the compact node decodes to the explicit one, absent children included
+            present = int(nodes[w]["child"][1]) >> 26
+            assert present in (0x3, 0x7, 0xF), (what, w, present)
+            for c in range(4):
+                ref = int(explicit[w]["child"][c])
+                assert ((present >> c) & 1) == (ref != NONE), (what, w, c)
+                if ref == NONE:
+                    continue
+                got = _compact_ref(nodes[w], c)
+                if got & LEAF:
+                    assert int(leaf_boxes[got & 0x03FFFFFF, 3:4].view(np.uint32)[0]) == ref, (what, w, c)
+                else:
+                    assert got == ref, (what, w, c)
+        assert any(int(n["child"][1]) >> 26 != 0xF for n in nodes), what  # the scene does hold nodes with absent children
+        for i in range(300):
+            o = (target + rng.normal(size=3) * 20.0).astype(np.float32)
+            d = (target + rng.normal(size=3).astype(np.float32) * np.float32(2.0e-5) - o).astype(np.float32)
+            leaves, phantoms, steps = _walk_compact(nodes, root, o, d, True, 50 * len(nodes) + 50)
+            assert phantoms == 0 and steps <= len(nodes), (what, i, phantoms, steps)  # every node at most once: the walk ends
+            assert len(leaves) == len(set(leaves)), (what, i)
+            _, old_phantoms, _ = _walk_compact(nodes, root, o, d, False, 50 * len(nodes) + 50)
+            hazard_seen = hazard_seen or old_phantoms > 0
+    assert hazard_seen  # without the mask these very rays do walk into absent children
