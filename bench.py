@@ -347,29 +347,19 @@ def main():
     # a GPU cannot use more lanes than it owns pixels, and even one GPU with the whole 1080p frame has only eight items per
     # resident lane: the last ones run while most of the chip has nothing left (7 % of config 2).  So the passes of a pixel
     # are split into S chunks (rt_render_opts.sample_split: the same samples, chunk means combined in fixed order, defined
-    # identically in the oracle; the image moves by ~1e-7), S the power of two <= 64 that gives >= 64 work items per resident
-    # lane: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs.  Measured on one GPU: the whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8
-    # share 27.9 ms at S = 1, 11.1 at S = 32 / 64 (an eighth of the whole frame's best: 10.9).  RT_BENCH_SPLIT overrides.
-    # A chunk is at least 16 passes on one GPU and 4 when the frame is sharded over several (a rank's share of config 4 at 8 GPUs is
-    # 256 passes of 259 k pixels: 146 / 140 / 135 ms at S = 16 / 32 / 64 on one GPU's share, ideal 124: profiles/r03k_mesh1m_share*.txt).
-    lanes = 262144
-    split = 1
-    min_chunk = 16 if world == 1 else 4
-    while (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else world)) * split < 64 * lanes and split < 64 and split < SPP // min_chunk:
-        split *= 2
-    if os.environ.get("RT_BENCH_SPLIT"):
-        split = int(os.environ["RT_BENCH_SPLIT"])
-    opts.sample_split = split
-    if abi_devices and len(abi_devices) > 1:
-        opts.sample_split = 0  # the library picks the split for its device list (same rule, rt_hip.h)
+    # identically in the oracle; the image moves by ~1e-7).  S is the LIBRARY's automatic choice (sample_split = 0), asked for
+    # through rt_scene_auto_sample_split -- the one rule the C ABI, this file and tests/test_gpu_parity.py::test_full_size_*
+    # share: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs on config 2.  RT_BENCH_SPLIT overrides (A/B measurements).
     if "shard" in w:  # one rank's shard of a larger job: render it packed, nothing to gather
         shard_index, shard_count = w["shard"]
     else:
         shard_index, shard_count = rank, world
     sopts = D.shard_opts(opts, shard_index, shard_count)
-    gather = D.ShardGather(opts, rank, world, comm_device) if ("shard" not in w and not abi_devices) else None
     if abi_devices:
         sopts = opts  # whole frame, RT_LAYOUT_FRAME: the scene shards over its devices by itself
+    split = int(os.environ["RT_BENCH_SPLIT"]) if os.environ.get("RT_BENCH_SPLIT") else scene.auto_sample_split(sopts)
+    opts.sample_split = sopts.sample_split = split
+    gather = D.ShardGather(opts, rank, world, comm_device) if ("shard" not in w and not abi_devices) else None
     n_shard_floats = hb.output_floats(sopts)
     shard = torch.zeros(n_shard_floats // 3, 3, dtype=torch.float32, device=device) if gather is None else gather.new_shard_buffer()
     frame = torch.empty(HEIGHT * WIDTH, 3, dtype=torch.float32, device=comm_device) if (rank == 0 and gather is not None) else None
@@ -533,7 +523,8 @@ def main():
                                        if world > 1 else
                                        (f"one process, devices {abi_devices} through rt_scene_create_multi (tiles t % {len(abi_devices)}, in-process gather)"
                                         if abi_devices else ("1 GPU" + (f", shard {w['shard'][0]} of {w['shard'][1]}" if "shard" in w else "")))),
-                       "sample_split": split if not abi_devices else "library (rt_scene_create_multi)",
+                       "sample_split": launch["sample_split"],
+                       "sample_split_rule": "RT_BENCH_SPLIT" if os.environ.get("RT_BENCH_SPLIT") else "rt_scene_auto_sample_split (the library's automatic choice)",
                        "ms_per_step_host_frame": host_frame_ms,
                        "value_host_frame": (samples_per_step / host_frame_ms / 1e3) if host_frame_ms else None,
                        "host_frame_note": "rt_render: the same step with the frame copied to a host buffer (SURVEY 8(d)'s wall-seconds of rt_render); "

@@ -184,7 +184,8 @@ typedef struct rt_render_opts {
 	int32_t output_layout;  /* rt_output_layout */
 	/* 1 (default): a pixel's passes are folded strictly in pass order, `mean += (pass-mean)/i`,
 	 * the reference's accumulation (src/main.rs:179-185).  0 = automatic: the power of two <= 64 that gives this device
-	 * >= 64 work items per resident lane (16 for one GPU at 1080p; rt_last_launch_info reports the choice).
+	 * >= 64 work items per resident lane (16 for one GPU at 1080p x 1024 passes; rt_scene_auto_sample_split states the rule,
+	 * rt_last_launch_info reports the choice).  The CPU checker (oracle/) takes explicit splits only: 0 is refused there.
 	 * S > 1: the passes of a pixel are split
 	 * into S contiguous chunks [floor(c*spp/S), floor((c+1)*spp/S)) that are folded independently
 	 * (each with its own i = 1..n_c) and combined in chunk order as
@@ -260,12 +261,17 @@ void rt_scene_destroy(rt_scene *scene);
  * and write them into the frame there; `rays_shot` is the sum over the devices.  The frame, `d_out_rgb`, `d_rays_shot` and
  * `hip_stream` belong to devices[0].  opts->shard_count must be 1 and the layout RT_LAYOUT_FRAME: the scene shards by itself.
  * opts->sample_split: 1 = every pixel folded strictly in pass order, so the frame equals the single-device frame bit for bit
- * (a device then cannot use more lanes than it owns pixels); 0 = automatic (the power of two <= 64 that gives >= 64 work items
- * per resident lane: 16, 32, 64, 64 for 1, 2, 4, 8 GPUs at 1080p); S > 1 as documented at rt_render_opts.  A list of ONE device is
+ * (a device then cannot use more lanes than it owns pixels); 0 = automatic (rt_scene_auto_sample_split below: 16, 32, 64, 64 for
+ * 1, 2, 4, 8 GPUs at 1080p x 1024 passes); S > 1 as documented at rt_render_opts.  A list of ONE device is
  * rt_scene_create.  The same device may be listed more than once (two members then share that GPU).  rt_check_hit[_index]
  * and the introspection calls use devices[0]. ---- */
 int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, rt_scene **out);
 int rt_scene_device_count(const rt_scene *scene, uint32_t *n_devices); /* 0 for a host-only scene */
+/* What opts->sample_split = 0 (automatic) resolves to for these options on this scene -- the ONE rule the library, bench.py and the
+ * tests share: the power of two S <= 64 that gives a device >= 64 work items (pixels x S) per resident lane (CUs x 1024), with
+ * chunks of at least 16 passes when the device renders the whole frame and at least 4 when the frame is sharded (over the
+ * scene's own devices, or opts->shard_count > 1).  rt_last_launch_info reports the split a render really used. */
+int rt_scene_auto_sample_split(const rt_scene *scene, const rt_render_opts *opts, uint32_t *split);
 
 /* introspection of what Bvh::new produced (for parity tests against the oracle) */
 int rt_scene_counts(const rt_scene *scene, uint64_t *n_nodes, uint64_t *n_primitives, uint64_t *n_lights);

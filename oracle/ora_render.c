@@ -627,7 +627,9 @@ int ora_render(const ora_scene *scene, const rt_camera *camera, const rt_render_
 	job.camera = camera;
 	job.opts = *opts;
 	job.mean = out_rgb;
-	job.split = opts->sample_split > 1 ? opts->sample_split : 1;
+	if (opts->sample_split == 0) /* 0 = "the device library picks" (rt_hip.h): a rule about GPUs; the checker takes the split it is told */
+		return fail(RT_ERR_INVALID_ARGUMENT, "sample_split 0 (automatic) is resolved by the device library (rt_scene_auto_sample_split): pass the split it chose");
+	job.split = opts->sample_split;
 	if (job.split > opts->samples_per_pixel)
 		return fail(RT_ERR_INVALID_ARGUMENT, "sample_split larger than samples_per_pixel");
 	job.acc = job.split > 1 ? (float *)calloc(opts->width * opts->height * 3, sizeof(float)) : NULL;

@@ -239,6 +239,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_wide_nodes",
     "rt_scene_get_leaf_boxes",
     "rt_scene_get_wide_nodes_compact",
+    "rt_scene_auto_sample_split",
     "rt_scene_get_leaf_boxes_compact",
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",

@@ -728,6 +728,31 @@ int shard_geometry(const rt_render_opts *o, ShardGeometry &g)
 
 } // namespace
 
+// sample_split = 0 (automatic), resolved.  ONE rule: the library (single- and multi-device scenes), bench.py and the tests all get
+// it from here (rt_scene_auto_sample_split).
+// A lane folds one work item at a time and an item is 1 / S of a pixel's passes: with whole pixels (S = 1) a device cannot use
+// more lanes than it owns pixels, and even one 1080p frame on one GPU is only eight items per resident lane, whose last ones run
+// while most of the chip has nothing left (7 % of config 2, 22 % of config 4).  S = the power of two that gives the device
+// >= 64 items per resident lane, at most 64 (a claim of 64 items then stays inside one tile: rt_render.hip acquire_tiles), with
+// chunks of at least 16 passes when the device holds the whole frame and at least 4 when the frame is sharded over `n_sharers`
+// devices (a device's 1/8 share of config 4 -- 256 passes of 259 k pixels -- needs chunks of 4 passes to keep its lanes supplied:
+// 146.0 / 140 / 134.5 ms at S = 16 / 32 / 64 on one GPU's share, ideal 124: profiles/r03k_mesh1m_share_splits.txt).  Measured on
+// one GPU, config 2: whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8 share 27.9 ms at S = 1, 11.1 at S = 32 / 64
+// (profiles/r03k_split_sweep.txt).
+static uint32_t auto_sample_split(int n_cus, uint64_t frame_pixels, uint64_t spp, uint32_t n_sharers)
+{
+	if (n_sharers == 0u)
+		n_sharers = 1u;
+	const uint64_t lanes = (uint64_t)(n_cus > 0 ? n_cus : 256) * 1024u;
+	const uint64_t min_chunk = n_sharers == 1u ? 16u : 4u;
+	uint32_t split = 1;
+	while ((frame_pixels / n_sharers) * split < 64 * lanes && split < 64u && split < spp / min_chunk)
+		split *= 2;
+	if (split > spp)
+		split = (uint32_t)(spp ? spp : 1u);
+	return split;
+}
+
 // Scene-owned frame buffers, grown on first use / larger frames only: rt_render needs one device frame,
 // rt_sample_image two device frames, two pinned host frames, a copy stream and its events.
 static int ensure_frame_buffers(rt_scene *s, uint64_t n_floats, bool progressive)
@@ -767,6 +792,19 @@ static int ensure_frame_buffers(rt_scene *s, uint64_t n_floats, bool progressive
 
 extern "C" {
 
+int rt_scene_auto_sample_split(const rt_scene *s, const rt_render_opts *o, uint32_t *split)
+{
+	if (!s || !o || !split)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	if (s->device == RT_DEVICE_NONE)
+		return fail(RT_ERR_NO_DEVICE, "host-only scene (RT_DEVICE_NONE): the split depends on the device's size");
+	if (o->shard_count == 0 || o->samples_per_pixel == 0)
+		return fail(RT_ERR_INVALID_ARGUMENT, "shard_count and samples_per_pixel must be >= 1");
+	const uint32_t members = (uint32_t)(1 + s->peers.size());
+	*split = auto_sample_split(s->n_cus, o->width * o->height, o->samples_per_pixel, members > 1u ? members : o->shard_count);
+	return RT_OK;
+}
+
 int rt_render_output_floats(const rt_render_opts *o, uint64_t *n_floats)
 {
 	ShardGeometry g;
@@ -804,21 +842,6 @@ int rt_shard_pixel_order(const rt_render_opts *o, uint64_t *out, uint64_t capaci
 // stream, the head on the caller's; the peers' shards are gathered into the head's HBM -- grouped ncclSend / ncclRecv
 // when the devices are distinct and RCCL is usable, hipMemcpyPeerAsync otherwise (same-device members: a plain copy) --
 // and one small kernel per shard writes them into the frame.  Nothing synchronises with the host. ----
-static int multi_sample_split(const rt_scene *head, const rt_render_opts *o, uint32_t n)
-{
-	// A lane folds one work item at a time and an item is 1 / S of a pixel's passes: with whole pixels (S = 1) a device cannot
-	// use more lanes than it owns pixels, and even one 1080p frame on one GPU is only eight items per resident lane, whose last
-	// ones run while most of the chip has nothing left (7 % of config 2).  The power of two of chunks that gives >= 64 items per
-	// resident lane, at most 64 (a claim of 64 items then stays inside one tile: rt_render.hip acquire_tiles) and at least 16
-	// passes per chunk.  Measured on one GPU, config 2: whole frame 93.4 ms at S = 1, 86.9 at S = 16; a 1/8 share 27.9 ms at
-	// S = 1, 11.1 at S = 32 / 64 (gpurun_out/r05n_split.log).
-	const uint64_t lanes = (uint64_t)head->n_cus * 1024u;
-	uint32_t split = 1;
-	while ((o->width * o->height / n) * split < 64 * lanes && split < 64u && split < o->samples_per_pixel / 16)
-		split *= 2;
-	return (int)split;
-}
-
 static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt_render_opts *o, float *d_out_rgb, uint64_t *d_rays_shot,
                                hipStream_t stream)
 {
@@ -830,10 +853,8 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 	rt_render_opts om = *o;
 	om.shard_count = n;
 	om.output_layout = RT_LAYOUT_SHARD;
-	if (om.sample_split == 0) // 0 = automatic on a multi-device scene; 1 = the reference's strictly sequential fold
-		om.sample_split = (uint32_t)multi_sample_split(head, o, n);
-	if (om.sample_split > om.samples_per_pixel)
-		om.sample_split = (uint32_t)om.samples_per_pixel;
+	if (om.sample_split == 0) // 0 = automatic; 1 = the reference's strictly sequential fold
+		om.sample_split = auto_sample_split(head->n_cus, o->width * o->height, o->samples_per_pixel, n);
 
 	std::vector<uint64_t> n_floats(n, 0), offset(n, 0);
 	uint64_t gather_total = 0;
@@ -1022,13 +1043,10 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	P.tiles_x = g.tiles_x;
 	P.tiles_y = g.tiles_y;
 	P.n_work = (uint32_t)g.n_work;
-	// sample_split 0 = automatic, on one device as on several (multi_sample_split: >= 64 work items per resident lane)
+	// sample_split 0 = automatic, on one device as on several (auto_sample_split: >= 64 work items per resident lane)
 	uint32_t split = o->sample_split;
-	if (split == 0u) {
-		split = (uint32_t)multi_sample_split(s, o, o->shard_count ? o->shard_count : 1u);
-		if (split > o->samples_per_pixel)
-			split = (uint32_t)o->samples_per_pixel;
-	}
+	if (split == 0u)
+		split = auto_sample_split(s->n_cus, o->width * o->height, o->samples_per_pixel, o->shard_count);
 	P.tile_log2_w = 0xFFFFFFFFu;
 	if (g.tile_w * g.tile_h == 64u && (g.tile_w & (g.tile_w - 1u)) == 0u && o->width < 65536u && o->height < 65536u &&
 	    (split & (split - 1u)) == 0u && split <= 64u)

@@ -220,6 +220,12 @@ class HipScene:
         _check(lib().rt_render_device(self._h, C.byref(camera), C.byref(opts), C.c_void_p(d_out_ptr),
                                       C.c_void_p(d_rays_ptr) if d_rays_ptr else None, C.c_void_p(stream)))
 
+    def auto_sample_split(self, opts):
+        """what opts.sample_split = 0 resolves to on this scene (rt_scene_auto_sample_split: the library's one rule)"""
+        v = C.c_uint32()
+        _check(lib().rt_scene_auto_sample_split(self._h, C.byref(opts), C.byref(v)))
+        return v.value
+
     def last_kernel_ms(self):
         ms, n = C.c_float(), C.c_uint32()
         _check(lib().rt_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
