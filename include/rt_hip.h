@@ -267,6 +267,27 @@ void rt_scene_destroy(rt_scene *scene);
  * and the introspection calls use devices[0]. ---- */
 int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_t n_devices, rt_scene **out);
 int rt_scene_device_count(const rt_scene *scene, uint32_t *n_devices); /* 0 for a host-only scene */
+/* How a multi-device scene moves its members' shards into devices[0] -- decided by rt_scene_create_multi (never by a render: no
+ * render initialises a communicator, opens a library or changes peer mappings, so rt_render_device is free of host
+ * synchronisation and HIP-graph capturable from its first call on):
+ *   RT_GATHER_NONE          one device, nothing to gather
+ *   RT_GATHER_RCCL          distinct devices: ncclCommInitAll at creation, grouped ncclSend / ncclRecv per frame.  The RCCL used
+ *                           is the file RT_HIP_RCCL_LIB names, else a copy already loaded into the process (e.g. PyTorch's),
+ *                           else the system's librccl.so.1
+ *   RT_GATHER_PEER          hipMemcpyPeerAsync with peer access devices[0] <- member enabled at creation: RT_HIP_NO_RCCL is set,
+ *                           RCCL is missing / lacks a symbol / refused the device list, or the list repeats a device
+ *   RT_GATHER_PEER_STAGED   the same, but at least one pair has no peer access: the runtime stages those copies through the
+ *                           host (correct, slower; the note names the devices)
+ *   RT_GATHER_SAME_DEVICE   every member shares devices[0]: plain device-to-device copies
+ * `note` (may be NULL) receives a NUL-terminated sentence saying why.  hipDeviceEnablePeerAccess failing on a pair that reports
+ * peer access as possible fails rt_scene_create_multi (RT_ERR_HIP, rt_last_error names the pair).
+ * STATUS: on hardware only RT_GATHER_SAME_DEVICE has run, and RT_GATHER_RCCL's call sequence against a stand-in library on one GPU
+ * (tests/cpp/fake_rccl.cpp); RCCL itself and peer copies between two GPUs have not (the test pool hands out one-GPU boxes). */
+typedef enum rt_gather_mode { RT_GATHER_NONE = 0, RT_GATHER_RCCL = 1, RT_GATHER_PEER = 2, RT_GATHER_PEER_STAGED = 3, RT_GATHER_SAME_DEVICE = 4 } rt_gather_mode;
+int rt_scene_gather_info(const rt_scene *scene, int *mode, char *note, uint64_t note_capacity);
+/* Which RCCL rt_scene_create_multi would bind, without touching a GPU: *usable = 1 when a library with all six entry points was
+ * found (and RT_HIP_NO_RCCL is not set); `note` names the file and how it was found, or what is missing. */
+int rt_rccl_probe(int *usable, char *note, uint64_t note_capacity);
 /* What opts->sample_split = 0 (automatic) resolves to for these options on this scene -- the ONE rule the library, bench.py and the
  * tests share: the power of two S <= 64 that gives a device >= 64 work items (pixels x S) per resident lane (CUs x 1024), with
  * chunks of at least 16 passes when the device renders the whole frame and at least 4 when the frame is sharded (over the

@@ -6,6 +6,7 @@ sizes against the values the C compiler reports.
 import ctypes as C
 
 RT_ABI_VERSION = 1
+RT_GATHER_NONE, RT_GATHER_RCCL, RT_GATHER_PEER, RT_GATHER_PEER_STAGED, RT_GATHER_SAME_DEVICE = 0, 1, 2, 3, 4
 
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT = -1
@@ -240,6 +241,8 @@ EXPORTED_SYMBOLS = [
     "rt_scene_get_leaf_boxes",
     "rt_scene_get_wide_nodes_compact",
     "rt_scene_auto_sample_split",
+    "rt_scene_gather_info",
+    "rt_rccl_probe",
     "rt_scene_get_leaf_boxes_compact",
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",

@@ -132,7 +132,10 @@ struct rt_scene {
 	size_t gather_floats = 0;
 	unsigned long long *d_gather_rays = nullptr; // head: [n] the members' ray counters
 	void *nccl_comms = nullptr;            // head: ncclComm_t[n] when the devices are distinct and RCCL is usable
-	int gather_mode = 0;                   // 0 undecided, 1 RCCL send/recv, 2 peer / same-device copies
+	int gather_mode = 0;                   // rt_gather_mode, decided when the scene is created (rt_scene_create_multi)
+	std::string gather_note;               // why (rt_scene_gather_info)
+	hipEvent_t ev_gathered = nullptr;      // head: the last render's gather + scatter have read every member's shard
+	bool gathered_once = false;
 };
 
 template <class T> static int upload(rt_scene *s, const T *src, size_t count, const T **dst)
@@ -147,11 +150,12 @@ template <class T> static int upload(rt_scene *s, const T *src, size_t count, co
 	return RT_OK;
 }
 
-// ---- RCCL, loaded on demand.  The gather of a multi-device render is the one collective of the path:
-// grouped ncclSend / ncclRecv of the members' shards into the head's device over xGMI.  The library is not a link-time
-// dependency (a process that already carries PyTorch's copy must not get a second one bound at load time); it is opened
-// when a scene over DISTINCT devices first renders.  If it is missing or refuses the device list, the same bytes move with
-// hipMemcpyPeerAsync. ----
+// ---- RCCL, loaded when a multi-device scene over DISTINCT devices is created.  The gather of a multi-device render is the one
+// collective of the path: grouped ncclSend / ncclRecv of the members' shards into the head's device over
+// xGMI.  The library is not a link-time dependency.  Look-up order: the file RT_HIP_RCCL_LIB names (tests: a stand-in that checks
+// the call pattern, tests/cpp/fake_rccl.cpp); a copy ALREADY LOADED into the process (RTLD_NOLOAD: a process that carries
+// PyTorch's librccl must not get a second one, with its own bootstrap threads and its own view of the devices); then the
+// system's.  If none is usable, or ncclCommInitAll refuses the device list, the same bytes move with hipMemcpyPeerAsync. ----
 struct RcclApi {
 	void *lib = nullptr;
 	int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
@@ -161,27 +165,58 @@ struct RcclApi {
 	int (*Send)(const void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
 	int (*Recv)(void *buf, size_t count, int datatype, int peer, void *comm, hipStream_t stream) = nullptr;
 	bool ok = false;
+	std::string origin; // which file, and how it was found (rt_scene_gather_info)
 };
-static RcclApi &rccl()
+static RcclApi load_rccl()
 {
-	static RcclApi api = [] {
-		RcclApi a;
-		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-			a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+	RcclApi a;
+	const char *forced = std::getenv("RT_HIP_RCCL_LIB");
+	if (forced && *forced) {
+		a.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+		a.origin = std::string(forced) + (a.lib ? " (RT_HIP_RCCL_LIB)" : " (RT_HIP_RCCL_LIB: cannot be loaded)");
+	} else {
+		static const char *const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		for (const char *name : names) { // a copy the process already carries first
+			a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+			if (a.lib) {
+				a.origin = std::string(name) + " (already loaded in this process)";
+				break;
+			}
+		}
+		for (const char *name : names) {
 			if (a.lib)
 				break;
+			a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (a.lib)
+				a.origin = std::string(name) + " (loaded on demand)";
 		}
 		if (!a.lib)
-			return a;
-		a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
-		a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
-		a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
-		a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
-		a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
-		a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
-		a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+			a.origin = "librccl not found";
+	}
+	if (!a.lib)
 		return a;
-	}();
+	a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(a.lib, "ncclCommInitAll"));
+	a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+	a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+	a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+	a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
+	a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
+	a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+	if (!a.ok)
+		a.origin += ": lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv";
+	return a;
+}
+static RcclApi &rccl()
+{
+	// (looked up once per process -- except under RT_HIP_RCCL_LIB, which tests change between scenes)
+	static RcclApi api;
+	static std::string key = "\x01";
+	const char *forced = std::getenv("RT_HIP_RCCL_LIB");
+	const std::string now = forced ? forced : "";
+	if (key != now) {
+		api = load_rccl();
+		key = now;
+	}
 	return api;
 }
 constexpr int kNcclFloat32 = 7; // ncclFloat32 of rccl.h
@@ -209,10 +244,98 @@ static void multi_release(rt_scene *s)
 		if (s->d_member_rays) (void)hipFree(s->d_member_rays);
 		if (s->ev_shard) (void)hipEventDestroy(s->ev_shard);
 		if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+		if (s->ev_gathered) (void)hipEventDestroy(s->ev_gathered);
 	}
 	s->d_shard = s->d_gather = nullptr;
 	s->d_gather_rays = s->d_member_rays = nullptr;
-	s->ev_shard = s->ev_begin = nullptr;
+	s->ev_shard = s->ev_begin = s->ev_gathered = nullptr;
+}
+
+// The transport of a multi-device scene's gather (rt_gather_mode in rt_hip.h), decided when the scene is created:
+//   members that share the head's device         a plain device-to-device copy
+//   distinct devices, RCCL usable                 ncclCommInitAll over the device list -> grouped ncclSend / ncclRecv
+//   otherwise (RT_HIP_NO_RCCL, no library, a library that lacks a symbol, ncclCommInitAll refusing the list)
+//                                                 hipMemcpyPeerAsync, with peer access enabled head <- member where the devices allow
+//                                                 it (RT_GATHER_PEER) and staged through the host by the runtime where they do not
+//                                                 (RT_GATHER_PEER_STAGED: correct, slower; the note says which pair)
+// A failure to ENABLE peer access that the device pair reports as possible is an error (the caller would silently get the slow path).
+static int multi_decide_gather(rt_scene *head, const std::vector<rt_scene *> &members)
+{
+	const uint32_t n = (uint32_t)members.size();
+	bool distinct = true, all_same = true;
+	for (uint32_t a = 0; a < n; ++a) {
+		all_same = all_same && members[a]->device == head->device;
+		for (uint32_t b = a + 1; b < n; ++b)
+			distinct = distinct && members[a]->device != members[b]->device;
+	}
+	head->gather_mode = RT_GATHER_NONE;
+	head->gather_note.clear();
+	if (n <= 1)
+		return RT_OK;
+	// RT_HIP_TEST_RCCL_ANY_LIST (tests only): offer RCCL a list with repeated devices too -- a real RCCL refuses it, which is the
+	// refusal path; the stand-in of tests/cpp/fake_rccl.cpp accepts it, which runs the grouped send / recv call pattern on one GPU
+	const bool test_any = std::getenv("RT_HIP_TEST_RCCL_ANY_LIST") != nullptr;
+	if (all_same && !test_any) {
+		head->gather_mode = RT_GATHER_SAME_DEVICE;
+		head->gather_note = "every member shares the head's device: device-to-device copies";
+		return RT_OK;
+	}
+	const bool offer = distinct || test_any;
+	std::string why;
+	if (std::getenv("RT_HIP_NO_RCCL") != nullptr)
+		why = "RT_HIP_NO_RCCL is set";
+	else if (!offer)
+		why = "the device list repeats a device (RCCL wants distinct devices)";
+	else if (!rccl().ok)
+		why = "RCCL unusable: " + rccl().origin;
+	else {
+		void **comms = new void *[n]();
+		std::vector<int> devs(n);
+		for (uint32_t m = 0; m < n; ++m)
+			devs[m] = members[m]->device;
+		const int rc = rccl().CommInitAll(comms, (int)n, devs.data());
+		(void)hipSetDevice(head->device); // (ncclCommInitAll visits every device)
+		if (rc == 0) {
+			head->nccl_comms = comms;
+			head->gather_mode = RT_GATHER_RCCL;
+			head->gather_note = "grouped ncclSend / ncclRecv, " + rccl().origin;
+			return RT_OK;
+		}
+		delete[] comms;
+		why = "ncclCommInitAll refused the device list (ncclResult " + std::to_string(rc) + "), " + rccl().origin;
+	}
+	// peer copies into the head's HBM: enable head <- member access where the pair supports it
+	head->gather_mode = RT_GATHER_PEER;
+	std::string staged;
+	for (uint32_t m = 1; m < n; ++m) {
+		if (members[m]->device == head->device)
+			continue;
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, head->device, members[m]->device) != hipSuccess)
+			can = 0;
+		if (can) {
+			if (hipSetDevice(head->device) != hipSuccess)
+				return fail(RT_ERR_HIP, "hipSetDevice failed");
+			const hipError_t e = hipDeviceEnablePeerAccess(members[m]->device, 0);
+			if (e == hipErrorPeerAccessAlreadyEnabled)
+				(void)hipGetLastError(); // (another scene, or the caller, enabled it: fine)
+			else if (e != hipSuccess)
+				return fail(RT_ERR_HIP, "multi-device scene: device " + std::to_string(head->device) + " can access device " + std::to_string(members[m]->device) +
+				                            " as a peer but hipDeviceEnablePeerAccess failed: " + hipGetErrorString(e));
+		} else {
+			head->gather_mode = RT_GATHER_PEER_STAGED;
+			staged += (staged.empty() ? "" : ", ") + std::to_string(members[m]->device);
+		}
+	}
+	head->gather_note = "hipMemcpyPeerAsync (" + why + ")";
+	if (all_same) {
+		head->gather_mode = RT_GATHER_SAME_DEVICE;
+		head->gather_note = "every member shares the head's device: device-to-device copies (" + why + ")";
+	}
+	if (!staged.empty())
+		head->gather_note += "; no peer access from device " + std::to_string(head->device) + " to device(s) " + staged + ": those copies are staged through the host";
+	(void)hipSetDevice(head->device);
+	return RT_OK;
 }
 
 // Lays a built scene out in the HBM of s->device (every array of rt_types.h) and creates the scene's stream, events and
@@ -537,11 +660,46 @@ int rt_scene_create_multi(const rt_scene_desc *desc, const int *devices, uint32_
 		}
 	}
 	if (hipSetDevice(head->device) != hipSuccess || hipEventCreateWithFlags(&head->ev_begin, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&head->ev_gathered, hipEventDisableTiming) != hipSuccess ||
 	    hipMalloc(reinterpret_cast<void **>(&head->d_gather_rays), n_devices * sizeof(unsigned long long)) != hipSuccess) {
 		rt_scene_destroy(head);
 		return fail(RT_ERR_HIP, "multi-device scene: event / counter allocation failed");
 	}
+	// ---- how the members' shards will reach the head: decided HERE, once, so that no render ever initialises a communicator,
+	// loads a library or changes a device's peer mappings (rt_render_device stays free of host synchronisation from its first
+	// call on, and graph-capturable) ----
+	rc = multi_decide_gather(head, members);
+	if (rc != RT_OK) {
+		rt_scene_destroy(head);
+		return rc;
+	}
 	*out = head;
+	return RT_OK;
+}
+
+int rt_rccl_probe(int *usable, char *note, uint64_t note_capacity)
+{
+	if (!usable)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	const RcclApi &a = rccl();
+	*usable = (a.ok && std::getenv("RT_HIP_NO_RCCL") == nullptr) ? 1 : 0;
+	if (note && note_capacity) {
+		const std::string text = std::getenv("RT_HIP_NO_RCCL") != nullptr ? std::string("RT_HIP_NO_RCCL is set") : a.origin;
+		std::strncpy(note, text.c_str(), (size_t)note_capacity - 1);
+		note[note_capacity - 1] = 0;
+	}
+	return RT_OK;
+}
+
+int rt_scene_gather_info(const rt_scene *s, int *mode, char *note, uint64_t note_capacity)
+{
+	if (!s || !mode)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	*mode = s->peers.empty() ? RT_GATHER_NONE : s->gather_mode;
+	if (note && note_capacity) {
+		std::strncpy(note, s->gather_note.c_str(), (size_t)note_capacity - 1);
+		note[note_capacity - 1] = 0;
+	}
 	return RT_OK;
 }
 
@@ -842,6 +1000,8 @@ int rt_shard_pixel_order(const rt_render_opts *o, uint64_t *out, uint64_t capaci
 // stream, the head on the caller's; the peers' shards are gathered into the head's HBM -- grouped ncclSend / ncclRecv
 // when the devices are distinct and RCCL is usable, hipMemcpyPeerAsync otherwise (same-device members: a plain copy) --
 // and one small kernel per shard writes them into the frame.  Nothing synchronises with the host. ----
+static int render_device_multi_enqueue(rt_scene *head, const std::vector<rt_scene *> &members, const rt_camera *camera, const rt_render_opts *o,
+                                       float *d_out_rgb, uint64_t *d_rays_shot, hipStream_t stream);
 static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt_render_opts *o, float *d_out_rgb, uint64_t *d_rays_shot,
                                hipStream_t stream)
 {
@@ -849,6 +1009,26 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 		return fail(RT_ERR_UNSUPPORTED, "a multi-device scene shards the frame over its own devices: shard_count must be 1 and the layout RT_LAYOUT_FRAME");
 	std::vector<rt_scene *> members{head};
 	members.insert(members.end(), head->peers.begin(), head->peers.end());
+	const int rc = render_device_multi_enqueue(head, members, camera, o, d_out_rgb, d_rays_shot, stream);
+	if (rc != RT_OK) {
+		// An error part-way leaves work in flight on the members' streams and the current device wherever the loop stood.  Drain
+		// the members (their next render must not race this one's leftovers), go back to the head's device, keep the first error.
+		const std::string first = g_error;
+		for (rt_scene *m : members) {
+			m->member_call = false;
+			if (m != head && hipSetDevice(m->device) == hipSuccess)
+				(void)hipStreamSynchronize(m->stream);
+		}
+		(void)hipSetDevice(head->device);
+		(void)hipGetLastError();
+		g_error = first;
+	}
+	return rc;
+}
+
+static int render_device_multi_enqueue(rt_scene *head, const std::vector<rt_scene *> &members, const rt_camera *camera, const rt_render_opts *o,
+                                       float *d_out_rgb, uint64_t *d_rays_shot, hipStream_t stream)
+{
 	const uint32_t n = (uint32_t)members.size();
 	rt_render_opts om = *o;
 	om.shard_count = n;
@@ -878,6 +1058,10 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 		head->gather_floats = gather_total;
 	}
 	HIP_TRY(hipEventRecord(head->ev_begin, stream)); // the peers start once the caller's stream has reached this call
+	// (a stream under HIP-graph capture may only wait on events recorded inside the capture: ev_gathered, which orders this render
+	// against the PREVIOUS one, is neither waited on nor recorded then -- replays of one graph are ordered by their launch stream)
+	hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+	const bool capturing = hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive;
 
 	// ---- every member renders its shard ----
 	for (uint32_t m = 0; m < n; ++m) {
@@ -896,6 +1080,10 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 		hipStream_t ms = m == 0 ? stream : mem->stream;
 		if (m > 0)
 			HIP_TRY(hipStreamWaitEvent(ms, head->ev_begin, 0));
+		// ... and once the PREVIOUS render's gather has read this member's shard (the head's own shard is read by the scatter on
+		// the previous caller stream): a caller that alternates streams between frames must not overwrite a shard in flight
+		if (head->gathered_once && !capturing)
+			HIP_TRY(hipStreamWaitEvent(ms, head->ev_gathered, 0));
 		om.shard_index = m;
 		mem->member_call = true;
 		const int rc = rt_render_device(mem, camera, &om, mem->d_shard, reinterpret_cast<uint64_t *>(mem->d_member_rays), ms);
@@ -906,29 +1094,9 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 			HIP_TRY(hipEventRecord(mem->ev_shard, ms));
 	}
 
-	// ---- gather the peers' shards (and ray counters) into the head's HBM ----
+	// ---- gather the peers' shards (and ray counters) into the head's HBM: the transport was fixed when the scene was created ----
 	HIP_TRY(hipSetDevice(head->device));
-	if (head->gather_mode == 0) { // decided once: RCCL needs distinct devices
-		bool distinct = true;
-		for (uint32_t a = 0; a < n; ++a)
-			for (uint32_t b = a + 1; b < n; ++b)
-				distinct = distinct && members[a]->device != members[b]->device;
-		head->gather_mode = 2;
-		if (n > 1 && distinct && rccl().ok && std::getenv("RT_HIP_NO_RCCL") == nullptr) {
-			void **comms = new void *[n]();
-			std::vector<int> devs(n);
-			for (uint32_t m = 0; m < n; ++m)
-				devs[m] = members[m]->device;
-			if (rccl().CommInitAll(comms, (int)n, devs.data()) == 0) {
-				head->nccl_comms = comms;
-				head->gather_mode = 1;
-			} else {
-				delete[] comms;
-			}
-			HIP_TRY(hipSetDevice(head->device));
-		}
-	}
-	if (head->gather_mode == 1) {
+	if (head->gather_mode == RT_GATHER_RCCL) {
 		void **comms = static_cast<void **>(head->nccl_comms);
 		if (rccl().GroupStart() != 0)
 			return fail(RT_ERR_HIP, "ncclGroupStart failed");
@@ -980,16 +1148,21 @@ static int render_device_multi(rt_scene *head, const rt_camera *camera, const rt
 			if (n_floats[m] == 0) {
 				HIP_TRY(hipMemsetAsync(head->d_gather_rays + m, 0, sizeof(unsigned long long), stream));
 			} else if (members[m]->device == head->device) {
-				if (m > 0 && head->gather_mode == 1)
+				if (m > 0 && head->gather_mode == RT_GATHER_RCCL)
 					HIP_TRY(hipStreamWaitEvent(stream, members[m]->ev_shard, 0));
 				HIP_TRY(hipMemcpyAsync(head->d_gather_rays + m, members[m]->d_member_rays, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
 			} else {
-				if (head->gather_mode == 1)
+				if (head->gather_mode == RT_GATHER_RCCL)
 					HIP_TRY(hipStreamWaitEvent(stream, members[m]->ev_shard, 0));
 				HIP_TRY(hipMemcpyPeerAsync(head->d_gather_rays + m, head->device, members[m]->d_member_rays, members[m]->device, sizeof(unsigned long long), stream));
 			}
 		}
 		HIP_TRY(launch_sum_u64(stream, head->d_gather_rays, n, reinterpret_cast<unsigned long long *>(d_rays_shot)));
+	}
+	// every member's shard and counter have been read once the caller's stream gets here
+	if (!capturing) {
+		HIP_TRY(hipEventRecord(head->ev_gathered, stream));
+		head->gathered_once = true;
 	}
 	return RT_OK;
 }

@@ -61,6 +61,13 @@ def _f3(v):
     return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
 
 
+def rccl_probe():
+    """(usable, note): which RCCL a multi-device scene would bind (rt_rccl_probe; touches no GPU)"""
+    usable, note = C.c_int(), C.create_string_buffer(512)
+    _check(lib().rt_rccl_probe(C.byref(usable), note, C.c_uint64(512)))
+    return bool(usable.value), note.value.decode()
+
+
 def device_count():
     return int(lib().rt_device_count())
 
@@ -219,6 +226,12 @@ class HipScene:
         """Asynchronous render into device memory (raw pointers, e.g. torch.Tensor.data_ptr())."""
         _check(lib().rt_render_device(self._h, C.byref(camera), C.byref(opts), C.c_void_p(d_out_ptr),
                                       C.c_void_p(d_rays_ptr) if d_rays_ptr else None, C.c_void_p(stream)))
+
+    def gather_info(self):
+        """(rt_gather_mode, why): how a multi-device scene moves its members' shards into devices[0] (rt_scene_gather_info)"""
+        mode, note = C.c_int(), C.create_string_buffer(512)
+        _check(lib().rt_scene_gather_info(self._h, C.byref(mode), note, C.c_uint64(512)))
+        return mode.value, note.value.decode()
 
     def auto_sample_split(self, opts):
         """what opts.sample_split = 0 resolves to on this scene (rt_scene_auto_sample_split: the library's one rule)"""
