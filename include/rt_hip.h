@@ -447,6 +447,12 @@ int rt_check_hit(rt_scene *scene, const rt_ray_desc *rays, uint64_t n_rays, rt_h
 int rt_check_hit_index(rt_scene *scene, const rt_ray_desc *rays, const uint64_t *object_index, uint64_t n_rays,
                        rt_hit_record *out);
 
+/* Division by a constant a launch knows beforehand (image size - 1, sky table resolution, pi, 2 pi): the kernels replace `x / c` by
+ * two fma steps on rc = RN(1 / c) where -- and only where -- the host has verified, by enumerating all 2^23 significands of x, that
+ * this returns the bits of the division (csrc/rt_build.cpp verified_reciprocal, csrc/rt_lean.h div_by_verified).  This call runs that
+ * verification for one divisor: *exact = 1 and *reciprocal = rc, or *exact = 0 (the kernels then keep the plain division).  No GPU. */
+int rt_selftest_division(float divisor, float *reciprocal, int *exact);
+
 /* ---- self-test of the kernels' arithmetic.  The render kernels compute `a / b`, `sqrtf` and the elementary functions
  * of include/rt_detmath.h through shorter instruction sequences wherever the operands make the omitted steps the identity
  * (raytracing-rust_amd/csrc/rt_lean.h).  This call runs both forms side by side ON `device` over 262 144 x n_per_thread random

@@ -243,6 +243,7 @@ EXPORTED_SYMBOLS = [
     "rt_scene_auto_sample_split",
     "rt_scene_gather_info",
     "rt_rccl_probe",
+    "rt_selftest_division",
     "rt_scene_get_leaf_boxes_compact",
     "rt_scene_set_traversal",
     "rt_scene_set_tuning",

@@ -441,6 +441,34 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 	D.sky.marginal_cdf = d_sky + (size_t)h.sky.sampler_res_y * (h.sky.sampler_res_x + 1u);
 	D.sky.guide = h.sky_guide_k ? d_guide : nullptr;
 	D.sky.guide_k = h.sky_guide_k;
+	{ // divisions by launch constants (rt_build.h verified_reciprocal; rt_lean.h div_by_verified)
+		float rc_pi = 0.0f, rc_tau = 0.0f;
+		if (!verified_reciprocal(RT_PI, &rc_pi) || !verified_reciprocal(RT_TAU, &rc_tau) || rc_pi != 1.0f / RT_PI || rc_tau != 1.0f / RT_TAU)
+			return bail(fail(RT_ERR_UNSUPPORTED, "self-check failed: division by pi / 2 pi through their reciprocals is not exact on this host (the kernels assume it)"));
+		D.sky.inv_res_ok = 0u;
+		D.sky.inv_res_x = D.sky.inv_res_y = 0.0f;
+		if (h.sky.sampler_res_x != 0 && h.sky.sampler_res_y != 0 && h.sky.sampler_res_x < (1u << 24) && h.sky.sampler_res_y < (1u << 24)) {
+			const bool ok_x = verified_reciprocal((float)h.sky.sampler_res_x, &D.sky.inv_res_x), ok_y = verified_reciprocal((float)h.sky.sampler_res_y, &D.sky.inv_res_y);
+			const bool ok = ok_x && ok_y;
+			D.sky.inv_res_ok = ok ? 1u : 0u;
+		}
+		// Lambertian numerators (rt_shade.h cosine_is_tame_): SolidColour textures, |colour x albedo| components zero or in
+		// [2^-30, 2^30], vertex normals finite and below 2^20
+		bool tame = true;
+		for (const DevMaterial &m : h.materials) {
+			if (m.type != RT_MAT_LAMBERTIAN)
+				continue;
+			tame = tame && m.tex_type == RT_TEX_SOLID;
+			for (int k = 0; k < 3; ++k) {
+				const float pr = std::fabs(m.tex_c1[k] * m.param);
+				tame = tame && (pr == 0.0f || (pr >= 0x1p-30f && pr <= 0x1p30f)); // false for NaN
+			}
+		}
+		for (const DevShade &sh : h.dev_shade)
+			for (int k = 0; k < 3; ++k)
+				tame = tame && std::fabs(sh.n0[k]) <= 0x1p20f && std::fabs(sh.n1[k]) <= 0x1p20f && std::fabs(sh.n2[k]) <= 0x1p20f;
+		D.lambert_tame = tame ? 1u : 0u;
+	}
 
 	void *p = nullptr;
 	if (hipMalloc(&p, sizeof(uint32_t)) != hipSuccess) return bail(fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc work counter"));
@@ -477,6 +505,7 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 				s->pair_tree = s->pair_tree && m.type == RT_MAT_LAMBERTIAN && m.tex_type == RT_TEX_SOLID;
 			}
 			s->pair_tree = s->pair_tree && h.materials[h.sky.material].type == RT_MAT_EMIT;
+			s->pair_tree = s->pair_tree && D.lambert_tame != 0u; // (rt_shade.h cosine_is_tame_: these kernels do not read the flag)
 			if (s->pair_tree) { // ... and that scene as kernel arguments, copied from the very records the other kernels read
 				DevPairScene &q = s->pair;
 				std::memcpy(q.c0min, n0.c0min, sizeof q.c0min); std::memcpy(q.c0max, n0.c0max, sizeof q.c0max);
@@ -1220,6 +1249,15 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	uint32_t split = o->sample_split;
 	if (split == 0u)
 		split = auto_sample_split(s->n_cus, o->width * o->height, o->samples_per_pixel, o->shard_count);
+	{ // u = (jitter + x) / (W - 1), v = (jitter + y) / (H - 1) by verified reciprocals (cached per divisor: rt_build.cpp)
+		float rw = 0.0f, rh = 0.0f;
+		const bool sized = o->width <= (1u << 24) && o->height <= (1u << 24);
+		const bool ok_w = sized && verified_reciprocal((float)(o->width - 1), &rw), ok_h = sized && verified_reciprocal((float)(o->height - 1), &rh);
+		const bool ok = ok_w && ok_h;
+		P.w1h1_ok = ok ? 1u : 0u;
+		P.inv_w1 = rw;
+		P.inv_h1 = rh;
+	}
 	P.tile_log2_w = 0xFFFFFFFFu;
 	if (g.tile_w * g.tile_h == 64u && (g.tile_w & (g.tile_w - 1u)) == 0u && o->width < 65536u && o->height < 65536u &&
 	    (split & (split - 1u)) == 0u && split <= 64u)
@@ -1936,6 +1974,14 @@ int rt_check_hit_index(rt_scene *s, const rt_ray_desc *rays, const uint64_t *obj
 	if (!object_index)
 		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
 	return check_common(s, rays, object_index, n_rays, out);
+}
+
+int rt_selftest_division(float divisor, float *reciprocal, int *exact)
+{
+	if (!reciprocal || !exact)
+		return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+	*exact = verified_reciprocal(divisor, reciprocal) ? 1 : 0;
+	return RT_OK;
 }
 
 int rt_selftest_lean(int device, uint64_t n_per_thread, uint64_t seed, uint64_t mismatches[RT_SELFTEST_LEAN_CLASSES])

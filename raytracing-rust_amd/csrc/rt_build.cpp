@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <unordered_map>
 #include <chrono>
 #include <cstring>
 #include <deque>
@@ -346,6 +348,56 @@ void camera_new(rt_camera *out, const float origin_[3], const float lookat_[3], 
 		dst[i][1] = all[i].y;
 		dst[i][2] = all[i].z;
 	}
+}
+
+// ---- division by a launch constant, verified (rt_build.h, rt_lean.h) ----
+// x / c costs eleven instructions on gfx950 (two v_div_scale, v_rcp, a Newton step, the quotient with two corrections,
+// v_div_fmas, v_div_fixup).  For a divisor known before the launch the reciprocal can be formed here, correctly rounded, and
+// one correction step is enough IF the rounding works out for that divisor -- which is decided by trying every significand:
+// the three operations are IEEE multiply / fma on both sides, so what holds here holds on the device, bit for bit.
+#if defined(__x86_64__)
+__attribute__((target("fma")))
+#endif
+static bool three_op_quotient_is_exact(float c, float rc)
+{
+	for (uint32_t m = 0; m < (1u << 23); ++m) {
+		float x;
+		const uint32_t u = (127u << 23) | m; // [1, 2): every other binade is this one times a power of two
+		std::memcpy(&x, &u, 4);
+		const float q0 = x * rc;
+		const float e = __builtin_fmaf(-c, q0, x);
+		const float q = __builtin_fmaf(e, rc, q0);
+		const float ref = x / c;
+		if (std::memcmp(&q, &ref, 4) != 0)
+			return false;
+	}
+	return true;
+}
+bool verified_reciprocal(float c, float *rc)
+{
+	static std::mutex mu;
+	static std::unordered_map<uint32_t, std::pair<bool, float>> cache;
+	uint32_t key;
+	std::memcpy(&key, &c, 4);
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		auto it = cache.find(key);
+		if (it != cache.end()) {
+			*rc = it->second.second;
+			return it->second.first;
+		}
+	}
+	const float a = std::fabs(c);
+	bool ok = a >= 0x1p-20f && a <= 0x1p32f; // false for NaN
+	const float r = ok ? 1.0f / c : 0.0f;     // correctly rounded (IEEE division on the host)
+#if defined(__x86_64__)
+	ok = ok && __builtin_cpu_supports("fma"); // (without hardware fma the enumeration would take seconds: plain division then)
+#endif
+	ok = ok && three_op_quotient_is_exact(c, r);
+	std::lock_guard<std::mutex> lock(mu);
+	cache[key] = {ok, r};
+	*rc = r;
+	return ok;
 }
 
 int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)

@@ -58,6 +58,11 @@ struct HostScene {
 // returns RT_OK or an rt_status; `err` receives the message
 int build_host_scene(const rt_scene_desc *desc, HostScene &out, std::string &err);
 
+// Division by a constant the kernels know before they start (rt_lean.h div_by_verified): for f32 c with |c| in [2^-20, 2^32] returns
+// true and rc = RN(1 / c) iff  fma(fma(-c, x * rc, x), rc, x * rc) == x / c  for EVERY significand x (2^23 of them, enumerated
+// here; the sequence is scale-invariant while nothing under- or overflows).  Cached per process.
+bool verified_reciprocal(float c, float *rc);
+
 // SimpleCamera::new  camera.rs:20-54
 void camera_new(rt_camera *out, const float origin[3], const float lookat[3], const float vup[3], float fov,
                 float aspect_ratio, float aperture, float focus_dist);

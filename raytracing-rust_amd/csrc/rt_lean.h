@@ -90,6 +90,22 @@ RT_FN float lean_atan2_portable(float y, float x)
 	return lean_atan2_with(y, x, [](float n, float d) { return n / d; }, [](float n, float d) { return n / d; });
 }
 
+// ---- x / c for a divisor the launch knows beforehand, c in [2^-20, 2^32], rc = RN(1 / c) formed on the host, which has also
+// VERIFIED (rt_build.cpp verified_reciprocal: every one of the 2^23 significands of x) that these three IEEE operations return the
+// correctly rounded quotient.  The sequence is scale-invariant while nothing under- or overflows, so it holds for x = 0, NaN
+// and 2^-60 <= |x| <= 2^60 (x = -0 comes back as +0 where the division returns -0: no use below feeds a -0 whose sign could
+// reach a pixel); each use says why its x is in that set (or tests it).  Three plain instructions instead of eleven
+// with a v_rcp_f32 among them: 7.5 issue cycles instead of 33 (profiles/r04_valu_issue.txt). ----
+RT_FN float div_by_verified(float x, float c, float rc)
+{
+	const float q0 = x * rc;
+	const float e = fmaf(-c, q0, x);
+	return fmaf(e, rc, q0);
+}
+// the two constants the shading code divides by: verified like any other (tests/test_lean_math.py asks the library), their
+// reciprocals are the compile-time IEEE quotients
+constexpr float kRcpPi = 1.0f / RT_PI, kRcpTau = 1.0f / RT_TAU;
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- device: hipcc's f32 division and square root without the identity steps (see the header comment) ----
 

@@ -73,6 +73,10 @@ constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 #endif
 constexpr uint32_t kStarveLimit = RT_STARVE_LIMIT;
 constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
+#ifndef RT_ACQUIRE_BATCH
+#define RT_ACQUIRE_BATCH 1
+#endif
+constexpr uint32_t kAcquireBatch = RT_ACQUIRE_BATCH; // coarse schedule, tile claims: lanes out of work are served once this many wait (or nothing else is left to do)
 #ifndef RT_DRAIN_LANES
 #define RT_DRAIN_LANES 6
 #endif
@@ -292,6 +296,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		T.guide = S.sky.guide;
 	}
 	T.guide_k = S.sky.guide_k;
+	T.inv_res = reinterpret_cast<KWords>(&K->S.sky.inv_res_ok);
 	// ---- tiny scenes (coarse schedule only): stage the whole scene into LDS, so the dependent loads
 	// of a walk (node -> primitive -> material -> texture) pay LDS latency instead of L1/L2 latency ----
 	uint32_t blob_words = 0;
@@ -332,6 +337,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		__syncthreads();
 	}
 
+#ifdef RT_STATS
+	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0, st_hist[8] = {};
+	// [0..8]: the sections of the coarse loop; [9..15]: their parts (tests/probes/gpu_stats_probe.py names them)
+	unsigned long long st_sect[16] = {}, st_mark = wall_clock64();
+	unsigned long long st_fine_clock[PH_COUNT + 1] = {};
+	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
+#endif
 	const bool sky_samplable = sky_can_sample(S);
 	constexpr int known_path = F::known_materials ? kMatLambertian : kMatRead; // the material a path continues from (see do_shade)
 
@@ -457,9 +469,18 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		// a round trip of its own)
 		const uint32_t w1 = here_(k->P.width - 1u), h1 = here_(k->P.height - 1u);
 		rt_rng_seed(&rng, seed, (uint64_t)pixel_index, sample_begin + chunk_begin + sample_local);
-		// (jitter + pixel) / (W - 1): the numerator is zero or in [2^-23, 2^31), the denominator in [1, 2^31]: tame (rt_lean.h)
-		const float u = div_tame_fix_(rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px, (float)w1);
-		const float v = 1.0f - div_tame_fix_(rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py, (float)h1);
+		RT_SECTION(15); // GEN: loads + stream seed
+		// (jitter + pixel) / (W - 1): the numerator is zero or in [2^-23, 2^31), the denominator in [1, 2^31]: tame (rt_lean.h) --
+		// and when the host has verified the two divisors (DevRenderParams::w1h1_ok), two fma steps on its reciprocals
+		const float jx = rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)px, jy = rt_rng_range_f32(&rng, 0.0f, 1.0f) + (float)py;
+		float u, v;
+		if (here_(k->P.w1h1_ok) != 0u) { // (wave-uniform)
+			u = div_by_verified(jx, (float)w1, k->P.inv_w1);
+			v = 1.0f - div_by_verified(jy, (float)h1, k->P.inv_h1);
+		} else {
+			u = div_tame_fix_(jx, (float)w1);
+			v = 1.0f - div_tame_fix_(jy, (float)h1);
+		}
 		// SimpleCamera::get_ray  camera.rs:57-63 (draws an unused `time`)
 		ray = ray_new<F>(cam_o, cam_ll + cam_h * u + cam_v * v - cam_o);
 		(void)rt_rng_f32(&rng);
@@ -602,10 +623,12 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			wo = ray.d;
 			hit = nh;
 			mat = nmat;
+			RT_SECTION(13); // primary arm: hit record
 			const V3 emission = emission_of_hit<F>(S, PS, mat, prim == kNoPrim, hit, wo);
 			Ray clone = ray; // scatter on a clone: draws consumed, ray discarded (mis.rs:25)
 			const bool exit = mat_scatter_ray<F>(S, mat, clone, hit, rng, known_new);
 			outp = outp + emission;
+			RT_SECTION(14); // primary arm: emission + scatter on a clone
 			if (exit) {
 				finish = true;
 				filter = false; // mis.rs:29-31 returns before the filter
@@ -621,6 +644,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			const float m_pdf = mat_scattering_pdf<F>(S, mat, hit, wo, m_wi, known_path);
 			const V3 le = emission_of_hit<F>(S, PS, nmat, prim == kNoPrim, hit /* the OLD hit, mis.rs:55 */, m_wi);
 			thr = thr * mat_eval_over_pdf<F>(S, mat, hit, wo, m_wi, known_path, PS);
+			RT_SECTION(11); // bounce arm: hit record, pdf, emission, throughput
 			if (!is_zero(le)) {
 				// bvh.get_samplable().contains(&index): Bvh.lights is exactly the primitives whose material
 				// is_light() (acceleration/mod.rs:84-88), so the hit primitive's material answers it
@@ -628,13 +652,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				if (on_light || (prim == kNoPrim && sky_samplable)) {
 					// Bvh::get_pdf_from_index  acceleration/mod.rs:299-318
 					const uint32_t n_l = F::lights ? S.n_lights : 0u;
-					const float divisor = (float)(sky_samplable ? n_l + 1u : n_l);
+					const uint32_t n_choices = sky_samplable ? n_l + 1u : n_l;
 					float l_pdf;
 					if (prim == kNoPrim) {
-						l_pdf = sky_pdf(S, T, m_wi) / divisor;
+						l_pdf = div_by_count(sky_pdf(S, T, m_wi), n_choices);
 					} else {
 						const PrimGeom g = load_prim<F>(S, prim);
-						l_pdf = prim_scattering_pdf<F>(g, hit.point, m_wi, nh) / divisor;
+						l_pdf = div_by_count(prim_scattering_pdf<F>(g, hit.point, m_wi, nh), n_choices);
 					}
 					const float mis_weight = power_heuristic(m_pdf, l_pdf);
 					outp = outp + thr * le * mis_weight;
@@ -642,6 +666,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 					outp = outp + thr * le;
 				}
 			}
+			RT_SECTION(12); // bounce arm: MIS weight of what was hit (sky_pdf)
 			if (mat_is_light<F>(S, nmat, known_new)) {
 				finish = true;
 			} else {
@@ -698,6 +723,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
 		if (pick_sky) {
 			L.l_wi = sky_sample(S, T, rng);
+			RT_SECTION(9); // LIGHT: sky_sample
 			sr = ray_new<F>(shadow_origin, L.l_wi);
 			L.t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
 			L.have_shadow = true;
@@ -751,6 +777,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				outp = outp + thr * mat_eval<F>(S, mat, hit, wo, L.l_wi, known_path, PS) * mis_weight * le / l_pdf;
 			}
 		}
+		RT_SECTION(10); // SCATTER: the light's contribution
 		// ---- material sampling  mis.rs:46-49.  scatter_ray reads only the incoming direction of
 		// the ray that produced `hit`, which is `wo` (mis.rs:21,82); `ray` held the shadow ray. ----
 		ray.d = wo;
@@ -1093,12 +1120,6 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		}
 	};
 
-#ifdef RT_STATS
-	unsigned long long st_iters[2] = {0, 0}, st_active[2] = {0, 0}, st_gen = 0, st_hist[8] = {};
-	unsigned long long st_sect[9] = {}, st_mark = wall_clock64();
-	unsigned long long st_fine_clock[PH_COUNT + 1] = {};
-	unsigned long long st_fine_iters[PH_COUNT] = {}, st_fine_active[PH_COUNT] = {};
-#endif
 	uint32_t wq_next = 0, wq_end = 0; // wave-uniform: this wave's private range of work items
 	// ... and, when a claim lies inside one tile (DevRenderParams::tile_log2_w), that tile's origin (x | y << 16) and the index,
 	// in this shard's pixel order, of the first pixel the claim covers: worked out once per claim, not once per item
@@ -1120,9 +1141,14 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
 		if (need == 0ull)
 			return;
+		// Serving an acquire event costs the WHOLE wave a round of scalar loads and some sixty instructions, and with short items
+		// (sample_split) an event is due in every third or fourth iteration, half of them for a single lane.  So a few needy lanes
+		// wait for company -- an idle lane costs 1/64 of an iteration -- as long as the wave has other work to vote on.
+		if (kAcquireBatch > 1u && (uint32_t)__popcll(need) < kAcquireBatch && __ballot(ph == PH_GEN || ph == PH_LIGHT) != 0ull)
+			return;
 		const KArgs k = kargs();
 		const uint32_t n = (uint32_t)__popcll(need);
-#ifdef RT_STATS
+#if defined(RT_STATS) && !defined(RT_STATS_NO_HIST)
 		if (lane == 0u)
 			atomicAdd(&g_hist[2][n], 1ull);
 #endif
@@ -1357,7 +1383,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			// About half of all SHADE outcomes end the sample; those lanes regenerate and stay in
 			// TRACE while continuing paths pile up for LIGHT, which runs once enough lanes wait. ----
 			const uint32_t n_light = (uint32_t)__popcll(__ballot(ph == PH_LIGHT));
-			const uint32_t n_trace = (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
+			// (between two iterations of the MIS loop with its two super-phases a lane is in GEN, LIGHT, NEED_PIXEL or DONE: the walk
+			// and both arms of SHADE run inside the super-phase that started them)
+			const uint32_t n_trace = (METHOD == 1 && RT_PQ_SPLIT) ? (uint32_t)__popcll(__ballot(ph == PH_GEN))
+			                                                      : (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
 			if (n_light + n_trace != 0u) {
 				const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u || (kStarveLimit != 0u && waited >= kStarveLimit));
 				waited = run_light ? 0u : waited + n_light;
@@ -1366,12 +1395,16 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 					if (!run_light) {
 						st_iters[0] += 1; st_active[0] += n_trace;
 						st_hist[(n_trace - 1u) >> 3] += 1; // PRIMARY iterations by the lanes that take part, in eighths of a wave
+#ifndef RT_STATS_NO_HIST // (three global atomics per iteration: left out when the section clocks are what is wanted)
 						atomicAdd(&g_hist[0][n_trace], 1ull);
 						atomicAdd(&g_hist[1][n_light], 1ull);
+#endif
 						st_gen += (unsigned long long)__popcll(__ballot(ph == PH_GEN));
 					} else {
 						st_iters[1] += 1; st_active[1] += n_light;
+#ifndef RT_STATS_NO_HIST
 						atomicAdd(&g_hist[3][n_light], 1ull);
+#endif
 					}
 				}
 	#endif
@@ -1490,6 +1523,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	if (lane == 0u) {
 		for (int k = 0; k < 9; ++k)
 			atomicAdd(&g_stats[40 + k], st_sect[k]);
+		if (!FINE) // (the fine schedule's clocks live in [50..57])
+			for (int k = 9; k < 16; ++k)
+				atomicAdd(&g_stats[40 + k], st_sect[k]);
 		for (int k = 0; k < 8; ++k)
 			atomicAdd(&g_stats[24 + k], st_hist[k]);
 		for (int k = 0; k <= PH_COUNT; ++k)

@@ -244,6 +244,16 @@ __device__ __forceinline__ uint32_t here_(uint32_t uniform)
 	return uniform;
 }
 
+// x / (float)n for a wave-uniform count n (the light-selection divisor, acceleration/mod.rs:299-318).  For a power of two --
+// one light or none besides the sky: the reference's scenes -- division and multiplication by the exact reciprocal are the
+// same correctly rounded operation on the same real number, whatever x is (zero, subnormal, infinite, NaN included).
+__device__ __forceinline__ float div_by_count(float x, uint32_t n)
+{
+	if ((n & (n - 1u)) == 0u && n != 0u) // (wave-uniform)
+		return x * __uint_as_float((127u - (uint32_t)__builtin_ctz(n)) << 23);
+	return x / (float)n;
+}
+
 // ---- statistics/distributions.rs ----
 // Distribution1D::sample :51-72 over a cdf of n+1 entries
 // `guide` (may be null; wave-uniform): guide_k upper-bound indices for this cdf, see DevSky in rt_types.h
@@ -284,11 +294,19 @@ __device__ __forceinline__ uint32_t dist1d_sample(const float *cdf, uint32_t n, 
 	return v > n - 1u ? n - 1u : v;
 }
 
+// (inv_res_ok, inv_res_x, inv_res_y) of DevSky, read from the kernel arguments WHERE THEY ARE USED: through `S` they would be
+// loaded in the prologue and hold three scalar registers for the life of the persistent loop (rt_render.hip, RenderArgs)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) uint32_t *KWords;
+#else
+typedef const uint32_t *KWords;
+#endif
 struct SkyTables {
 	const float *row_cdf;      // [res_y][res_x + 1]
 	const float *marginal_cdf; // [res_y + 1]
 	const uint8_t *guide;      // [res_y + 1][guide_k] or null
 	uint32_t guide_k;
+	KWords inv_res;            // -> DevSky::inv_res_ok in the kernarg segment (null: plain division)
 };
 
 __device__ __forceinline__ bool sky_can_sample(const DevScene &S) { return (S.sky.res_x | S.sky.res_y) != 0u; } // sky.rs:61-63
@@ -304,8 +322,13 @@ __device__ __forceinline__ float sky_pdf(const DevScene &S, const SkyTables &T, 
 	float phi = lean_atan2(wi.y, wi.x);
 	if (phi < 0.0f)
 		phi += 2.0f * kPi;
-	const float u = phi / (2.0f * kPi);
-	const float v = div_tame_fix_(theta, kPi); // acos returns zero, NaN or at least 2 asin(2^-12.5) = 3.4e-4
+	// u = phi / (2 pi) and v = theta / pi only pick a table cell below, and the divisions are by constants: the verified
+	// two-fma form (rt_lean.h div_by_verified; kRcpTau, kRcpPi) returns the bits of the division for phi, theta = 0, NaN or
+	// >= 2^-60 -- acos returns zero, NaN or at least 2 asin(2^-12.5) = 3.4e-4; atan2 (plus 2 pi when negative) lies in [0, 2 pi]
+	// and can be a tiny positive number, for which either form returns less than 2^-58: with a table of at most 2^24 cells the
+	// index below is 0 both ways.  (2.0f * kPi is kTau exactly: doubling a float is exact.)
+	const float u = div_by_verified(phi, kTau, kRcpTau);
+	const float v = div_by_verified(theta, kPi, kRcpPi);
 	const uint32_t rx = here_(S.sky.res_x), ry = here_(S.sky.res_y);
 	uint32_t ui = f32_as_index((float)rx * u);
 	uint32_t vi = f32_as_index((float)ry * v);
@@ -325,8 +348,22 @@ __device__ __forceinline__ V3 sky_sample(const DevScene &S, const SkyTables &T, 
 	const bool guided = T.guide_k != 0u;
 	const uint32_t sv = dist1d_sample(T.marginal_cdf, ry, guided ? T.guide + (size_t)ry * T.guide_k : nullptr, T.guide_k, rng);
 	const uint32_t su = dist1d_sample(T.row_cdf + (size_t)sv * (rx + 1u), rx, guided ? T.guide + (size_t)sv * T.guide_k : nullptr, T.guide_k, rng);
-	const float u = next_float((float)su + rt_rng_f32(&rng)) / (float)rx;
-	const float v = next_float((float)sv + rt_rng_f32(&rng)) / (float)ry;
+	// next_float(cell + r) is the smallest subnormal (cell = r = 0) or lies in [2^-24, 256]: the verified two-fma division applies
+	// (for the subnormal both forms return it unchanged when the table has one cell and zero otherwise: 2^-149 / n rounds to 0 for
+	// n >= 2, and x * rc underflows to 0 with a zero correction)
+	const float nu = next_float((float)su + rt_rng_f32(&rng)), nv = next_float((float)sv + rt_rng_f32(&rng));
+	float u, v;
+	KWords inv = T.inv_res;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+s"(inv)); // (a pointer the optimiser cannot see through: the loads below stay here)
+#endif
+	if (inv != nullptr && inv[0] != 0u) { // (wave-uniform)
+		u = div_by_verified(nu, (float)rx, __uint_as_float(inv[1]));
+		v = div_by_verified(nv, (float)ry, __uint_as_float(inv[2]));
+	} else {
+		u = nu / (float)rx;
+		v = nv / (float)ry;
+	}
 	const float phi = u * 2.0f * kPi;
 	const float theta = v * kPi;
 	// u and v lie in (0, 1 + 2^-20]: angles far inside lean_sincos's domain
@@ -432,6 +469,17 @@ template <class F> __device__ inline V3 tr_fresnel(const DevScene &S, const DevM
 	return fresnel(dot(wo, h), f0);
 }
 
+// May `cosine / pi` and `(colour x albedo) x cosine / pi` of a Lambertian (lambertian.rs:42-47) take the verified two-fma division
+// (rt_lean.h div_by_verified: exact for numerators that are zero or in [2^-60, 2^60])?  The cosine is max(dot, 0) >= 0 (NaN
+// becomes 0).  With DevScene::lambert_tame -- the host has checked that every Lambertian of the scene has a SolidColour whose
+// (colour x albedo) components are zero or in [2^-30, 2^30] and that every vertex normal is finite and below 2^20, so a cosine is
+// below 2^22 -- the numerators are tame whenever the cosine is zero or at least 2^-30.  The rare rest takes the plain operator.
+// (F::known_materials: the host launches those kernels only for scenes that pass the check -- rt_api.cpp, pair_tree)
+template <class F> __device__ __forceinline__ bool cosine_is_tame_(const DevScene &S, float c)
+{
+	return (F::known_materials || S.lambert_tame != 0u) && !(c < 0x1p-30f && c > 0.0f);
+}
+
 __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat) { return mat_handle_type(mat) == 0; }
 template <class F> __device__ __forceinline__ bool mat_is_light(const DevScene &S, uint32_t mat, int known) { return mat_type_<F>(mat, known) == 0; }
 template <class F> __device__ __forceinline__ bool mat_is_delta(const DevScene &S, uint32_t mat)
@@ -500,8 +548,12 @@ template <class F> __device__ __forceinline__ float mat_scattering_pdf(const Dev
 {
 	const DevMaterial &m = mat_record(S, mat);
 	const int type = mat_type_<F>(mat, known);
-	if (type == 1) // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
-		return fmax_(dot(wi, hit.normal), 0.0f) / kPi;
+	if (type == 1) { // lambertian.rs:42-44 -> bxdfs::lambertian::pdf
+		const float c = fmax_(dot(wi, hit.normal), 0.0f);
+		if (__builtin_expect(cosine_is_tame_<F>(S, c), 1))
+			return div_by_verified(c, kPi, kRcpPi);
+		return c / kPi;
+	}
 	if (F::cmat && type == 2) { // trowbridge_reitz.rs:52-60
 		const float a = tr_pdf(m.param, -wo, wi, hit.normal);
 		return a == 0.0f ? INFINITY : a;
@@ -515,7 +567,11 @@ template <class F> __device__ __forceinline__ V3 mat_eval(const DevScene &S, uin
 	const int type = mat_type_<F>(mat, known);
 	if (type == 1) { // lambertian.rs:45-47
 		const LambertRec L = lambert_record<F>(S, m, mat, wo, hit.point, ps);
-		return L.colour * L.albedo * fmax_(dot(hit.normal, wi), 0.0f) / kPi;
+		const float c = fmax_(dot(hit.normal, wi), 0.0f);
+		const V3 num = L.colour * L.albedo * c;
+		if (__builtin_expect(cosine_is_tame_<F>(S, c), 1)) // numerators zero or in [2^-60, 2^60]: see cosine_is_tame_
+			return v3(div_by_verified(num.x, kPi, kRcpPi), div_by_verified(num.y, kPi, kRcpPi), div_by_verified(num.z, kPi, kRcpPi));
+		return num / kPi;
 	}
 	if (!F::cmat)
 		return v3s(0.0f);

@@ -161,7 +161,11 @@ struct DevSky {
 	// same index Distribution1D::sample's binary search returns (distributions.rs:51-72), in about
 	// three dependent reads instead of seven.  guide_k is a power of two, so (uint)(num * guide_k) is exact.
 	const uint8_t *guide;      // (res_y + 1) * guide_k
-	uint32_t guide_k, pad_guide;
+	uint32_t guide_k;
+	// x / res_x and x / res_y as two fma steps on the host's correctly rounded reciprocals -- set only when the host has verified,
+	// by enumeration, that this returns the bits of the division for every x (rt_build.h verified_reciprocal); 0: plain division
+	uint32_t inv_res_ok;
+	float inv_res_x, inv_res_y;
 };
 
 struct DevScene {
@@ -188,6 +192,9 @@ struct DevScene {
 	uint32_t n_nodes4;
 	uint32_t narrow_only;      // RT_TUNE_WALK = 1: every ray takes the two-child walk (tests, A/B measurements)
 	uint32_t has_triangles;
+	// every Lambertian record's (colour x albedo) components are zero or >= 2^-30 (host check): with a cosine that is zero or
+	// >= 2^-30 the numerators of Lambertian::eval are then zero or >= 2^-60, where the verified division by pi applies (rt_shade.h)
+	uint32_t lambert_tame;
 	DevSky sky;
 };
 
@@ -243,6 +250,10 @@ struct DevRenderParams {
 	// items then lies inside ONE tile -- 64 / S of its pixels times their S chunks -- whose origin is worked out once per claim
 	// (rt_render.hip, acquire_tiles).  0xFFFFFFFF: any other tiling or split, every item is decoded on its own (chunk-major).
 	uint32_t tile_log2_w;
+	// (jitter + x) / (W - 1) and (jitter + y) / (H - 1) of the pixel loop (random_sampler.rs:55-59) by verified reciprocals
+	// (rt_build.h verified_reciprocal); w1h1_ok = 0: plain division
+	uint32_t w1h1_ok;
+	float inv_w1, inv_h1;
 };
 
 } // namespace rt

@@ -19,6 +19,12 @@ for name in ("rtweekend1", "overshadowed"):
     tot = max(1, sum(sect))
     names = ["vote+claim", "P:gen", "P:walk", "P:shade", "Q:light", "Q:shadow walk", "Q:scatter", "Q:walk", "Q:shade"]
     print("   wave wall-clock share: " + "  ".join(f"{nm} {100*v/tot:.1f}%" for nm, v in zip(names, sect)))
+    # parts of those sections (round 4): a named part ends where the next stamp of its section begins
+    sub = [out[40 + k] for k in range(9, 16)]
+    sub_names = ["Q:light:sky_sample", "Q:scatter:light contribution", "Q:shade:hit+pdf+emission+thr", "Q:shade:MIS weight (sky_pdf)", "P:shade:hit record",
+                 "P:shade:emission+clone scatter", "P:gen:loads+seed"]
+    tot2 = max(1, sum(sect) + sum(sub))
+    print("   with the parts split out (share of everything): " + "  ".join(f"{nm} {100*v/tot2:.1f}%" for nm, v in zip(names + sub_names, sect + sub)))
     hist = [out[24 + k] for k in range(8)]
     print("   PRIMARY iterations by participating lanes (1-8, 9-16, ... 57-64): " + "  ".join(f"{100*v/max(1,sum(hist)):.1f}%" for v in hist))
     n = 1920 * 1080 * int(o.samples_per_pixel)

@@ -41,3 +41,37 @@ def test_lean_elementary_functions_equal_detmath(lean_check):
     assert set(res) == {"sincos", "acos", "atan2_grid", "atan2_ratio"}
     for name, (n, bad) in res.items():
         assert n > 1000 and bad == 0, (name, n, bad)
+
+
+def test_division_by_launch_constants_is_verified(hb):
+    """csrc/rt_lean.h div_by_verified: x / c as q0 = x * rc, q = fma(fma(-c, q0, x), rc, q0) with rc = RN(1 / c) -- used by the
+    kernels only for divisors the HOST has verified over all 2^23 significands (csrc/rt_build.cpp verified_reciprocal; the C ABI
+    exposes that check as rt_selftest_division).  Here: pi and 2 pi (the kernels' compile-time reciprocals must be the verified
+    ones), the image sizes and sky resolutions of the BASELINE configs; divisors outside [2^-20, 2^32] are refused; and an
+    independent numpy emulation of the three operations agrees with the division on a million random numerators."""
+    import ctypes as C
+    import numpy as np
+    lib = hb.lib()
+
+    def check(c):
+        rc, ok = C.c_float(), C.c_int()
+        assert lib.rt_selftest_division(C.c_float(c), C.byref(rc), C.byref(ok)) == 0
+        return bool(ok.value), np.float32(rc.value)
+
+    pi, tau = np.float32(3.14159274101257324219), np.float32(6.28318548202514648438)
+    for c in (pi, tau):
+        ok, rc = check(float(c))
+        assert ok and rc == np.float32(1.0) / c
+    rng = np.random.default_rng(3)
+    for c in (1919.0, 1079.0, 399.0, 224.0, 4095.0, 100.0, 1.0, 2.0, 63.0, 35.0, float(pi)):
+        ok, rc = check(c)
+        assert ok, c  # (every divisor tried so far passes; a failing one would only cost speed: the kernels keep the plain division)
+        c32 = np.float32(c)
+        x = (rng.uniform(0.5, 2.0, 1 << 20) * 2.0 ** rng.integers(-40, 40, 1 << 20)).astype(np.float32)
+        x[:3] = [0.0, np.float32(2.0 ** -60), np.float32(2.0 ** 60)]  # (-0 comes back as +0: no caller feeds one whose sign matters)
+        q0 = (x * rc).astype(np.float32)
+        e = (np.float64(x) - np.float64(c32) * np.float64(q0)).astype(np.float32)   # fma(-c, q0, x): the exact remainder fits an f32
+        q = (np.float64(e) * np.float64(rc) + np.float64(q0)).astype(np.float32)
+        assert np.array_equal(q.view(np.uint32), (x / c32).astype(np.float32).view(np.uint32)), c
+    for c in (0.0, 1.0e-10, 1.0e12, float("nan"), float("inf")):
+        assert not check(c)[0], c
