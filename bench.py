@@ -51,7 +51,13 @@ HBM_ACHIEVABLE_GBS = 6290.0
 CLOCK_HZ = 2.4e9               # max engine clock (MI355X_MICROARCH.md chip-level parameters)
 SIMDS = 256 * 4
 VALU_ISSUE_PEAK = SIMDS * CLOCK_HZ / 2.0  # one wave64 VALU instruction per 2 cycles per SIMD-32
-VALU_PLAIN_CYCLES_MEASURED = 2.75  # what a SIMD really spends per plain VALU wave-instruction with 2 or 4 waves on it (profiles/r03_valu_issue.txt)
+# What a SIMD really spends per wave-instruction with four waves on it, MEASURED with in-kernel cycle counters (s_memtime /
+# s_memrealtime around the loop: tests/probes/microbench/valu_issue.hip -> profiles/r04_valu_issue.txt; the chip held 2.2 - 2.39 GHz
+# there, not the 1.75 GHz round 3's wall-clock reading would have needed to be consistent with 2 cycles):
+VALU_PLAIN_CYCLES_MEASURED = 2.5     # v_fma / v_xor / v_mov / v_cndmask (2.27 with eight waves; one wave alone 5.1)
+VALU_HALF_RATE_CYCLES_MEASURED = 4.25  # v_mul_lo/hi_u32, v_mad_u64_u32, v_pk_*_f32
+VALU_TRANS_CYCLES_MEASURED = 8.25    # v_rcp_f32, v_sqrt_f32
+SALU_CYCLES_MEASURED = 2.15          # a scalar instruction of the same wave, interleaved 1:1 with VALU: 4.65 per pair, i.e. NOT free
 # dependent random record fetches, every lane its own chain (tests/microbench/random_fetch.hip ->
 # profiles/r01d_random_fetch_microbench.txt): 115 G/s when the set is L2-resident, 57 G/s beyond L2
 L2_FETCH_CEILING_RESIDENT = 115.0e9
@@ -407,6 +413,23 @@ def main():
             scene.render(cam, sopts)
         host_frame_ms = (time.perf_counter() - t0) / n_host * 1e3
 
+    # What the kernels that are NOT compiled for this scene's own tree and materials deliver on the same workload: the headline
+    # workload's tree is one node over two single-sphere leaves, for which the library picks rt::FeatPair; RT_TUNE_FEATURE_SET = 0
+    # names the general spheres-only set instead (same pixels: tests/test_gpu_parity.py::test_every_kernel_variant...).  Untimed
+    # for `value`: a few extra steps on a second handle of the same scene.
+    general = None
+    if world == 1 and name == "rtweekend1" and not abi_devices:
+        g2 = hb.HipScene(scene_desc, device=local_rank)
+        g2.set_tuning(abi.RT_TUNE_FEATURE_SET, 0)
+        best = None
+        for _ in range(4):
+            g2.render_device(cam, sopts, shard_dev.data_ptr(), d_rays.data_ptr(), stream.cuda_stream)
+            ms = g2.last_kernel_ms()[0]
+            best = ms if best is None else min(best, ms)
+        general = {"kernel": g2.last_launch_info()["kernel"], "kernel_ms": best, "value_general_kernel": WIDTH * HEIGHT * SPP / best / 1e3,
+                   "note": "RT_TUNE_FEATURE_SET=0: the spheres-only kernels that serve any sphere scene, best of 4 untimed-for-value launches"}
+        g2.close()
+
     if rank == 0:
         samples_per_step = (WIDTH * HEIGHT // (w["shard"][1] if "shard" in w else 1)) * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
@@ -432,22 +455,35 @@ def main():
             vps = counters.get("valu_wave_instructions_per_sample")
             achieved = vps * launch_samples / k_s if vps else None
             roof.update({"achieved": achieved / 1e9 if achieved else None, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G VALU wave-instructions/s",
-                         "frac": min(achieved / VALU_ISSUE_PEAK, 1.0) if achieved else None,
+                         "frac": achieved / VALU_ISSUE_PEAK if achieved else None,
                          "valu_wave_instructions_per_sample": vps, "lane_utilisation": counters.get("valu_lane_utilisation"),
                          **useful_valu_share(launch["kernel"]),
-                         "note": "scene and sky tables live in SGPRs/LDS; HBM sees 12 B/pixel per frame (traffic), so the bound is VALU "
-                                 "issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"})
-            # `peak` is the nominal rate.  MEASURED on this chip (profiles/r03_valu_issue.txt: tests/probes/microbench/valu_issue.hip,
-            # 2 and 4 waves per SIMD issuing nothing else): a plain VALU instruction holds its SIMD for 2.75 cycles, integer multiplies
-            # and packed-f32 for 4.5, v_rcp / v_sqrt for 8.25.  Against those, with the STATIC instruction mix of this kernel's binary
-            # (profiles/valu_census.json; cold paths included, so an estimate), the same `achieved` is:
+                         "note": "scene and sky tables live in SGPRs/LDS; the only HBM traffic is the output: with sample_split S every work item "
+                                 f"writes its 12-byte chunk mean and combine_chunks_kernel reads them back and writes the frame ({launch['sample_split']} x 12 + 12 B "
+                                 f"per pixel written, {launch['sample_split']} x 12 read = {(2 * launch['sample_split'] + 1) * 12 * WIDTH * HEIGHT / 1e6:.0f} MB per frame, `traffic` "
+                                 "is what the PMC counters saw), so the bound is VALU issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"})
+            # `peak` is the nominal rate (one wave64 VALU instruction per 2 cycles per SIMD).  MEASURED on this chip with in-kernel
+            # cycle counters (profiles/r04_valu_issue.txt), four waves per SIMD issuing nothing else: a plain VALU instruction holds
+            # its SIMD for 2.5 cycles, integer multiplies and packed f32 for 4.25, v_rcp / v_sqrt for 8.25 -- and a SCALAR instruction
+            # of the same waves for about 2.15 (v_fma + s_alu interleaved 1:1: 4.65 cycles per pair).  `issue_model` adds that up for
+            # this kernel: dynamic VALU and SALU counts (PMC) x those costs, the VALU mix from the static census of the binary
+            # (profiles/valu_census.json; cold paths included, so an estimate), against the SIMD cycles the launch had.
             mix = roof.get("valu_census_issue_cycles_static_mix")
-            roof["measured_issue_ceiling"] = {
-                "cycles_per_plain_instruction": VALU_PLAIN_CYCLES_MEASURED,
-                "frac_of_plain_instruction_ceiling": min(achieved / (VALU_ISSUE_PEAK * 2.0 / VALU_PLAIN_CYCLES_MEASURED), 1.0) if achieved else None,
-                "cycles_per_instruction_static_mix": mix,
-                "frac_of_static_mix_ceiling": min(achieved / (VALU_ISSUE_PEAK * 2.0 / mix), 1.0) if (achieved and mix) else None,
-                "source": "profiles/r03_valu_issue.txt + profiles/valu_census.json"}
+            sps = counters.get("salu_wave_instructions_per_sample")
+            clock = (counters.get("effective_clock_ghz") or CLOCK_HZ / 1e9) * 1e9
+            have = SIMDS * clock * k_s
+            need_valu = vps * launch_samples * (mix or VALU_PLAIN_CYCLES_MEASURED) if vps else None
+            need_salu = sps * launch_samples * SALU_CYCLES_MEASURED if sps else None
+            roof["issue_model"] = {
+                "cycles": {"plain_valu": VALU_PLAIN_CYCLES_MEASURED, "half_rate_valu": VALU_HALF_RATE_CYCLES_MEASURED, "transcendental": VALU_TRANS_CYCLES_MEASURED,
+                           "salu": SALU_CYCLES_MEASURED, "valu_static_mix": mix},
+                "salu_wave_instructions_per_sample": sps,
+                "effective_clock_ghz_when_profiled": counters.get("effective_clock_ghz"),
+                "frac_of_plain_valu_ceiling": achieved / (VALU_ISSUE_PEAK * 2.0 / VALU_PLAIN_CYCLES_MEASURED) if achieved else None,
+                "simd_cycles_needed_over_available_valu_only": need_valu / have if need_valu else None,
+                "simd_cycles_needed_over_available_valu_plus_salu": (need_valu + need_salu) / have if (need_valu and need_salu) else None,
+                "source": "profiles/r04_valu_issue.txt + profiles/valu_census.json + the PMC profile named in counters_source",
+                "note": "a value near 1 means the SIMDs' instruction issue is what the launch waits for: only fewer, or cheaper, instructions help"}
         elif w["bound"] == "l2_request_rate":
             rps = counters.get("l2_read_requests_per_sample")
             hit = counters.get("l2_hit_rate")
@@ -456,10 +492,10 @@ def main():
             if hit is not None:  # harmonic blend of the two measured ceilings at the kernel's own L2 hit rate
                 ceiling = 1.0 / (hit / L2_FETCH_CEILING_RESIDENT + (1.0 - hit) / L2_FETCH_CEILING_BEYOND)
             roof.update({"achieved": achieved / 1e9 if achieved else None, "peak": L2_FETCH_CEILING_RESIDENT / 1e9, "unit": "G L1->L2 read requests/s",
-                         "frac": min(achieved / L2_FETCH_CEILING_RESIDENT, 1.0) if achieved else None,
+                         "frac": achieved / L2_FETCH_CEILING_RESIDENT if achieved else None,
                          "l2_read_requests_per_sample": rps, "l2_hit_rate": hit,
                          "blended_ceiling_at_this_hit_rate": ceiling / 1e9 if ceiling else None,
-                         "frac_of_blended_ceiling": min(achieved / ceiling, 1.0) if (achieved and ceiling) else None,
+                         "frac_of_blended_ceiling": achieved / ceiling if (achieved and ceiling) else None,
                          "lane_utilisation": counters.get("valu_lane_utilisation"),
                          "note": "every node step is a dependent, effectively random 64-byte fetch; peak = measured dependent-random-fetch "
                                  "rate of an L2-resident set (115 G/s), 57 G/s beyond L2 (profiles/r01d_random_fetch_microbench.txt)"})
@@ -485,7 +521,7 @@ def main():
             achieved = wb * launch_samples / k_s / 1e9 if wb else None
             measured = counters.get("hbm_bytes_per_launch") / counters.get("kernel_ms_when_measured") / 1e6 if counters.get("hbm_bytes_per_launch") else None
             roof.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": min(achieved / HBM_PEAK_GBS, 1.0) if achieved else None,
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None,
                          "achievable_peak": HBM_ACHIEVABLE_GBS,
                          "fabric_GBps_from_pmc": measured, "fabric_frac_of_peak": measured / HBM_PEAK_GBS if measured else None,
                          "fabric_frac_of_achievable": measured / HBM_ACHIEVABLE_GBS if measured else None,
@@ -496,7 +532,7 @@ def main():
                                  "of this build: above the requested bytes because a node step uses 48 bytes of the 128-byte line it arrives in "
                                  "(the line count, not the byte count, is what HBM serves).  fabric_frac_of_achievable is NOT the binding limit, "
                                  "though it reads like one: eight-child nodes moved 22 % fewer lines over the fabric and the launch got 6 % slower "
-                                 "(profiles/r04w8_mesh10m_pmc.json against r03n; DESIGN.md section 5 (5)): the launch follows lane-level 16-byte "
+                                 "(profiles/archive_r03/r04w8_mesh10m_pmc.json against r03n_mesh10m_pmc.json there; HISTORY.md): the launch follows lane-level 16-byte "
                                  "fetches and VALU instructions, HBM is the nearest roofline"})
         ab = w["bytes"]
         ap = os.path.join(ROOT, "profiles", "algorithmic_bytes.json")  # the oracle's own count, when it has been made for this workload
@@ -530,6 +566,8 @@ def main():
                        "host_frame_note": "rt_render: the same step with the frame copied to a host buffer (SURVEY 8(d)'s wall-seconds of rt_render); "
                                           "`value` is the HBM-resident rate the bench contract asks for",
                        "abi_devices": abi_devices,
+                       "general_kernel": general,
+                       "value_general_kernel": general["value_general_kernel"] if general else None,
                        "samples_per_step": samples_per_step, "rays_shot_per_step": int(rays.item()),
                        "scene_build_s": build_s},
             "roofline": roof,

@@ -89,6 +89,11 @@ RT_HD uint32_t rt_mulhi_u32(uint32_t a, uint32_t b)
 
 RT_HD void rt_philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_PHILOX_ROLLED)
+	/* (unrolled on the device: left to itself hipcc keeps a five-trip loop whose counter, compare and branch are scalar
+	 * instructions that take vector issue slots from the SIMD -- profiles/r04_valu_issue.txt) */
+	_Pragma("unroll")
+#endif
 	for (int round = 0; round < 10; ++round) {
 		/* the full 64-bit products: on gfx950 ONE v_mad_u64_u32 each instead of a v_mul_hi_u32 / v_mul_lo_u32 pair */
 		const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c[0];

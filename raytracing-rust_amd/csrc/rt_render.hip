@@ -69,7 +69,7 @@ constexpr uint32_t kLightPhaseThreshold = RT_LIGHT_PHASE_THRESHOLD;
 // cheap items and hands them to a few lanes at a time (stats build, config 2 at S = 16: 37 % of PRIMARY iterations ran with
 // 17 - 24 lanes while 40 - 47 waited).  0 = off.
 #ifndef RT_STARVE_LIMIT
-#define RT_STARVE_LIMIT 128 // config 2 at S = 16, same box: off 87.0 ms, 48 / 96 / 192 / 384 -> 80.6 / 80.0 / 79.8 / 80.1 (gpurun_out/r05w); at S = 1 within noise
+#define RT_STARVE_LIMIT 128 // config 2 at S = 16, same box: off 87.0 ms, 48 / 96 / 192 / 384 -> 80.6 / 80.0 / 79.8 / 80.1 (profiles/r03_ab_logs/r05w_split_ab.log); at S = 1 within noise
 #endif
 constexpr uint32_t kStarveLimit = RT_STARVE_LIMIT;
 constexpr uint32_t kClaim = 64; // work items a wave claims per atomic
@@ -721,18 +721,25 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				pick_light = true;
 		}
 		const V3 shadow_origin = hit.point + 0.0001f * hit.normal;
+		// the two arms only choose the direction; the shadow ray itself (Ray::new: some fifty instructions) is formed once, after
+		// them, for the lanes of both -- inside each arm the wave paid for it twice whenever its lanes disagreed on the pick
+		PrimGeom g;
+		g.type = g.material = 0u;
+		g.p0 = g.p1 = g.p2 = v3s(0.0f);
 		if (pick_sky) {
 			L.l_wi = sky_sample(S, T, rng);
 			RT_SECTION(9); // LIGHT: sky_sample
-			sr = ray_new<F>(shadow_origin, L.l_wi);
 			L.t_limit = __uint_as_float(0x7FC00000u); // NaN: any t > 0 occludes
 			L.have_shadow = true;
 			L.shadow_is_sky = true;
 		} else if (pick_light) {
 			L.skip = S.lights[light_slot];
-			const PrimGeom g = load_prim<F>(S, L.skip);
+			g = load_prim<F>(S, L.skip);
 			L.l_wi = prim_sample_visible_from_point<F>(g, hit.point, rng);
+		}
+		if (pick_sky || pick_light)
 			sr = ray_new<F>(shadow_origin, L.l_wi);
+		if (pick_light) {
 			float lt;
 			if (prim_t<F>(g, sr, lt) && lt > 0.0f) { // Bvh::check_hit_index  mod.rs:231-242
 				L.t_limit = lt;
@@ -1178,7 +1185,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			const uint32_t xy = from_old ? old_xy : wq_xy;
 			const uint32_t in = w & 63u;
 			// (the other single-sweep layout -- a claim = all 64 pixels of the tile for ONE chunk, claims tile-major -- measured the
-			// same to 0.3 % at every split: gpurun_out/r05v)
+			// same to 0.3 % at every split: profiles/r03_ab_logs/r05v_split_ab.log)
 			const uint32_t wp = (from_old ? old_pbase : wq_pbase) + (in >> log2_s); // the pixel, in this shard's order
 			const uint32_t c = in & ((1u << log2_s) - 1u);                            // ... and which of its chunks
 			const uint32_t in_tile = wp & 63u;

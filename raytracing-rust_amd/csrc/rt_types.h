@@ -62,7 +62,7 @@ static_assert(sizeof(DevNode) == 64, "DevNode must be one 64-byte record");
 
 // Wide node: up to four children of a collapsed subtree of the reference tree in ONE 64-byte record.  What bounds a
 // walk over a big tree on this chip is the rate at which a CU's texture addresser / L1 serves DIVERGENT 16-byte lane
-// loads (about 0.75 per cycle per CU; profiles/r02c_*): the cost of a walk is the number of 16-byte pieces its lanes
+// loads (about 0.75 per cycle per CU; profiles/archive_r01_r02/r02c_*): the cost of a walk is the number of 16-byte pieces its lanes
 // fetch, so the node carries as much tree per piece as it can: child boxes are 8-bit offsets on a per-node grid
 // (origin + q * 2^exp per axis), rounded OUTWARD, i.e. conservative supersets of the reference boxes.  Conservative boxes
 // only decide where the walk goes; whether a leaf's primitives are tested is decided by the leaf's EXACT reference
@@ -207,7 +207,7 @@ struct DevScene {
 // of Bvh::get_intersection_candidates): a per-lane slot selects between the two entries by `slot == slot0`.  Filled by the
 // host from the arrays the other kernels read (rt_api.cpp), so both routes see the same bits.  Measured same-box at 256
 // spp: 24.0 -> 23.55 ms; the same block read through the kernarg pointer at each use (seven rounds per iteration instead of
-// two) measured 24.2 (gpurun_out/r05b, r05c).
+// two) measured 24.2 (profiles/r03_ab_logs/r05b_small_ab.log, r05c_small_ab.log).
 struct alignas(64) DevPairScene {
 	float c0min[3], c0max[3], c1min[3], c1max[3]; // DevNode's child boxes
 	uint32_t slot0, slot1;                        // primitive slot of each leaf

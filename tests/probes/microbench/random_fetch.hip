@@ -46,21 +46,26 @@ template <int R> static void run(const float4 *buf, uint32_t n_rec, uint32_t str
 
 int main(int argc, char **argv)
 {
-	const size_t bytes = 512u << 20;
+	// Round 4: the access shape the big-tree walk really has since the compact wide node -- THREE 16-byte pieces of a 64-byte
+	// record (48 of 64 B) per node step, TWO of a 32-byte record per leaf box -- at the kernels' 4 waves per SIMD, over sets that are
+	// L2-resident per XCD (2 MB), split between L2 and the Infinity Cache (8, 32, 128 MB: the 1 M-triangle tree is 30 MB of nodes +
+	// 32 MB of leaf boxes + 48 MB of primitives) and beyond the Infinity Cache (1 GB: the 10 M-triangle tree is 0.3 + 0.3 + 0.5 GB).
+	// The round-1 figures (64 of 64 B at 8 MB and 134 MB) are kept for comparison.
+	const size_t bytes = (size_t)1 << 30;
 	float4 *buf;
 	float *out;
-	hipMalloc(&buf, bytes);
+	if (hipMalloc(&buf, bytes) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
 	hipMemset(buf, 0, bytes);
 	hipMalloc(&out, 4096 * 256 * sizeof(float));
-	for (int waves_per_simd : {2, 3, 4, 8}) {
+	for (int waves_per_simd : {4, 8}) {
 		const int blocks = 256 * waves_per_simd; // 256 CUs x (4 waves per block = 1 per SIMD)
 		char what[64];
-		for (size_t mb : {8, 128}) {
+		for (size_t mb : {2, 8, 32, 128, 1024}) {
 			snprintf(what, sizeof what, "%d waves/SIMD", waves_per_simd);
-			run<2>(buf, (uint32_t)((mb << 20) / 32), 32, blocks, out, what);
-			run<4>(buf, (uint32_t)((mb << 20) / 64), 64, blocks, out, what);
-			run<8>(buf, (uint32_t)((mb << 20) / 128), 128, blocks, out, what);
-			run<4>(buf, (uint32_t)((mb << 20) / 128), 128, blocks, out, what);
+			run<3>(buf, (uint32_t)((mb << 20) / 64), 64, blocks, out, what);  // the compact wide node
+			run<2>(buf, (uint32_t)((mb << 20) / 32), 32, blocks, out, what);  // a leaf box
+			run<4>(buf, (uint32_t)((mb << 20) / 64), 64, blocks, out, what);  // (round 1's shape)
+			run<3>(buf, (uint32_t)((mb << 20) / 48), 48, blocks, out, what);  // a primitive record: 48 of 48 B, straddling lines
 		}
 	}
 	return 0;

@@ -105,6 +105,10 @@ if "SQ_INSTS_VALU" in c:
     summary["valu_wave_instructions_per_second"] = c["SQ_INSTS_VALU"] / (kernel_ms * 1e-3)
     summary["valu_issue_peak_per_second"] = bench.VALU_ISSUE_PEAK  # 1024 SIMD-32 x one wave64 VALU op per 2 cycles
     summary["valu_issue_fraction_of_peak"] = summary["valu_wave_instructions_per_second"] / bench.VALU_ISSUE_PEAK
+if "SQ_INSTS_SALU" in c:  # scalar instructions take vector issue slots from their SIMD too (profiles/r04_valu_issue.txt)
+    summary["salu_wave_instructions_per_sample"] = c["SQ_INSTS_SALU"] / samples_per_launch
+    summary["smem_wave_instructions_per_sample"] = c.get("SQ_INSTS_SMEM", 0.0) / samples_per_launch
+    summary["lds_wave_instructions_per_sample"] = c.get("SQ_INSTS_LDS", 0.0) / samples_per_launch
 if "TCP_TCC_READ_REQ_sum" in c:
     summary["l2_read_requests_per_sample"] = c["TCP_TCC_READ_REQ_sum"] / samples_per_launch
     summary["l2_read_requests_per_second"] = c["TCP_TCC_READ_REQ_sum"] / (kernel_ms * 1e-3)
@@ -119,7 +123,9 @@ kp = os.path.join(dst, "kernel_counters.json")
 kc = json.load(open(kp)) if os.path.exists(kp) else {}
 entry = {"source": f"profiles/{tag}_pmc.json", "source_hash": summary["source_hash"], "kernel_ms_when_measured": kernel_ms,
          "kernel": (launches.get("kernel_name") or render["Name"]).replace("void ", "").split("(")[0].replace("> >", ">>")}
-for k in ("valu_wave_instructions_per_sample", "valu_lane_utilisation", "l2_read_requests_per_sample", "l2_hit_rate"):
+for k in ("valu_wave_instructions_per_sample", "valu_lane_utilisation", "l2_read_requests_per_sample", "l2_hit_rate",
+          "salu_wave_instructions_per_sample", "smem_wave_instructions_per_sample", "lds_wave_instructions_per_sample", "effective_clock_ghz",
+          "wave_cycle_shares"):
     if k in summary:
         entry[k] = summary[k]
 if "fetch_bytes_as_reported" in summary:
