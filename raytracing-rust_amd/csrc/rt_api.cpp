@@ -433,6 +433,7 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 	D.stack_depth = h.stack_depth;
 	s->stack_depth_narrow = h.stack_depth_narrow;
 	D.has_triangles = h.has_triangles ? 1u : 0u;
+	D.single_light = h.dev_lights.size() == 1 ? h.dev_lights[0] : kNoPrim;
 	D.sky.texture = h.sky.texture;
 	D.sky.material = mat_handle_make(h.sky.material, h.materials[h.sky.material].type, h.materials[h.sky.material].tex_type);
 	D.sky.res_x = h.sky.sampler_res_x;

@@ -421,10 +421,8 @@ __device__ __forceinline__ bool beyond(float t_entry, float t_best, const float 
 // with the reference's predicate, choose where to go next.  limit_valid/t_limit: prune children
 // entered beyond t_limit (PRUNE only).
 template <bool PRUNE, bool OVF>
-__device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp,
-                                            bool limit_valid, float t_limit)
+__device__ __forceinline__ uint32_t descend_view(const NodeView &n, const StackMem &M, const Ray &r, uint32_t *stk, int &sp, bool limit_valid, float t_limit)
 {
-	const NodeView n = load_node(S, node);
 	float t0, t1;
 	bool h0 = aabb_does_int(n.c0min, n.c0max, r, t0);
 	bool h1 = aabb_does_int(n.c1min, n.c1max, r, t1);
@@ -452,6 +450,12 @@ __device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M
 		return kRefDone;
 	--sp;
 	return stack_load<OVF>(M, stk, sp);
+}
+template <bool PRUNE, bool OVF>
+__device__ __forceinline__ uint32_t descend(const DevScene &S, const StackMem &M, const Ray &r, uint32_t node, uint32_t *stk, int &sp,
+                                            bool limit_valid, float t_limit)
+{
+	return descend_view<PRUNE, OVF>(load_node(S, node), M, r, stk, sp, limit_valid, t_limit);
 }
 
 // ---- the wide walk ----
@@ -816,6 +820,11 @@ __device__ __forceinline__ void trace_closest(const DevScene &S, const DevScene 
 	int sp = 0;
 	const bool wide = PRUNE && S.nodes4 != nullptr && S.narrow_only == 0u && ray_is_regular(r);
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
+	// The ROOT of the two-child tree is the same record for every lane of every walk: under the exhaustive walk (no lane takes
+	// the wide tree) it arrives through one scalar load and its two box tests read it from SGPRs -- one per-lane LDS / L1 round
+	// trip less at the head of each walk's chain of dependent fetches (config 3: three walks per sample)
+	if (!PRUNE && !ref_is_leaf(S.root_ref)) // (wave-uniform)
+		node = descend_view<PRUNE, OVF>(load_node_uniform(SU.nodes + S.root_ref), M, r, stk, sp, false, 0.0f);
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
 			node = wide ? descend4<PRUNE, OVF>(S, M, r, node, stk, sp, best_prim != kNoPrim, best_t)
@@ -877,6 +886,8 @@ __device__ __forceinline__ bool trace_any(const DevScene &S, const DevScene &SU,
 	int sp = 0;
 	const bool wide = PRUNE && S.nodes4 != nullptr && S.narrow_only == 0u && ray_is_regular(r);
 	uint32_t node = wide ? S.root4_ref : S.root_ref;
+	if (!PRUNE && !ref_is_leaf(S.root_ref)) // the root through a scalar load: see trace_closest
+		node = descend_view<PRUNE, OVF>(load_node_uniform(SU.nodes + S.root_ref), M, r, stk, sp, false, 0.0f);
 	while (node != kRefDone) {
 		while (!ref_is_leaf(node) && node != kRefDone)
 			node = wide ? descend4<PRUNE, OVF>(S, M, r, node, stk, sp, limited, t_limit)

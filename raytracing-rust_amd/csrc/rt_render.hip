@@ -733,8 +733,13 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			L.have_shadow = true;
 			L.shadow_is_sky = true;
 		} else if (pick_light) {
-			L.skip = S.lights[light_slot];
-			g = load_prim<F>(S, L.skip);
+			if (S.single_light != kNoPrim) { // (wave-uniform) the one light: its record through scalar loads, from the scene in global memory
+				L.skip = S.single_light;
+				g = load_prim_uniform<F>(&S_global.prims[L.skip]);
+			} else {
+				L.skip = S.lights[light_slot];
+				g = load_prim<F>(S, L.skip);
+			}
 			L.l_wi = prim_sample_visible_from_point<F>(g, hit.point, rng);
 		}
 		if (pick_sky || pick_light)
@@ -769,8 +774,19 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			} else { // sample_light  mis.rs:117-133 (`ray` still is the shadow ray)
 				Hit lh;
 				uint32_t lm;
-				make_hit<F>(S, L.skip, sr, L.t_limit, lh, lm);
-				const PrimGeom g = load_prim<F>(S, L.skip);
+				PrimGeom g;
+				if (S.single_light != kNoPrim) { // (wave-uniform) as in do_light; a sphere's hit record needs nothing but this record
+					g = load_prim_uniform<F>(&S_global.prims[L.skip]);
+					if (!F::tri || g.type == kPrimSphere) {
+						make_sphere_hit(g.p0, g.p1.x, sr, L.t_limit, lh);
+						lm = g.material;
+					} else {
+						make_hit<F>(S, L.skip, sr, L.t_limit, lh, lm);
+					}
+				} else {
+					make_hit<F>(S, L.skip, sr, L.t_limit, lh, lm);
+					g = load_prim<F>(S, L.skip);
+				}
 				const float p = prim_scattering_pdf<F>(g, hit.point, L.l_wi, lh);
 				if (p > 0.0f) {
 					le = mat_get_emission<F>(S, lm, lh, L.l_wi);

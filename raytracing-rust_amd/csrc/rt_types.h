@@ -195,6 +195,9 @@ struct DevScene {
 	// every Lambertian record's (colour x albedo) components are zero or >= 2^-30 (host check): with a cosine that is zero or
 	// >= 2^-30 the numerators of Lambertian::eval are then zero or >= 2^-60, where the verified division by pi applies (rt_shade.h)
 	uint32_t lambert_tame;
+	// Bvh.lights has exactly one entry: its primitive slot (else kNoPrim).  Every lane that samples "a light" then samples THE
+	// light, whose record is wave-uniform: it arrives through scalar loads (rt_render.hip do_light / do_scatter)
+	uint32_t single_light;
 	DevSky sky;
 };
 

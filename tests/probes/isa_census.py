@@ -64,13 +64,13 @@ def census(ops):
                saveexec=sum(n for k, n in c.items() if 'saveexec' in k))
     out['useful_valu_share'] = round(1.0 - moves / valu, 4) if valu else None
     # issue-cost classes (profiles/r03_valu_issue.txt, tests/probes/microbench/valu_issue.hip, 4 waves per SIMD): a plain 32-bit
-    # VALU instruction occupies its SIMD for 2.75 cycles, 32-bit integer multiplies / v_mad_u64_u32 / packed-f32 for 4.5,
+    # VALU instruction occupies its SIMD for 2.5 cycles (profiles/r04_valu_issue.txt: in-kernel cycle counters, four waves per SIMD), 32-bit integer multiplies / v_mad_u64_u32 / packed-f32 for 4.25,
     # v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos for 8.25
     half = sum(n for k, n in c.items() if re.match(r'v_(mul_lo_u32|mul_lo_i32|mul_hi_u32|mul_hi_i32|mul_u32_u24|mul_i32_i24|mad_u32_u24|mad_i32_i24|mad_u64_u32|mad_i64_i32|pk_)', k))
     trans = sum(n for k, n in c.items() if re.match(r'v_(rcp|rsq|sqrt|exp|log|sin|cos)_', k))
     out['valu_half_rate'] = half
     out['valu_transcendental'] = trans
-    out['valu_issue_cycles_static_mix'] = round(((valu - half - trans) * 2.75 + half * 4.5 + trans * 8.25) / valu, 4) if valu else None
+    out['valu_issue_cycles_static_mix'] = round(((valu - half - trans) * 2.5 + half * 4.25 + trans * 8.25) / valu, 4) if valu else None
     return out
 
 def write_committed_census():
@@ -84,7 +84,7 @@ def write_committed_census():
     csrc = os.path.join(root, "raytracing-rust_amd", "csrc")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "rt_render.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
                         "-fno-gpu-rdc", "-Wno-unused-function", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "--cuda-device-only", "-S",
                         os.path.join(csrc, "rt_render.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         ks, meta = parse(out)
