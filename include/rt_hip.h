@@ -187,12 +187,14 @@ typedef struct rt_render_opts {
 	 * >= 64 work items per resident lane (16 for one GPU at 1080p x 1024 passes; rt_scene_auto_sample_split states the rule,
 	 * rt_last_launch_info reports the choice).  The CPU checker (oracle/) takes explicit splits only: 0 is refused there.
 	 * S > 1: the passes of a pixel are split
-	 * into S contiguous chunks [floor(c*spp/S), floor((c+1)*spp/S)) that are folded independently
-	 * (each with its own i = 1..n_c) and combined in chunk order as
-	 * (sum_c mean_c * n_c) / spp in f32.  Same samples, same streams, a different summation order:
-	 * the image changes at the 1e-7 level.  It exists for parallelism and for balance: without it a render cannot use
-	 * more lanes than it has pixels (8 GPUs at 1080p have one pixel per lane), and even one GPU ends a 1080p frame with
-	 * most of its lanes idle while the last whole pixels finish (7 - 29 % of the launch on the BASELINE workloads). */
+	 * into S contiguous chunks [floor(c*spp/S), floor((c+1)*spp/S)); each chunk's passes are SUMMED in pass order (f32, from +0),
+	 * the chunk sums are added in chunk order and the total is divided by spp once: (sum_c sum_c) / spp.  Same samples, same
+	 * streams, a different association than the running mean: the image changes at the 1e-7 level (tests hold the whole 1080p
+	 * frame of the BASELINE configs to < 1e-4 of the sequential fold).  It exists for parallelism and for balance: without it a
+	 * render cannot use more lanes than it has pixels (8 GPUs at 1080p have one pixel per lane), and even one GPU ends a 1080p
+	 * frame with most of its lanes idle while the last whole pixels finish (7 - 29 % of the launch on the BASELINE workloads).
+	 * (Rounds 1 - 3 folded each chunk as a running mean and combined sum_c mean_c * n_c: three IEEE divisions per sample that the
+	 * chunked form has no use for -- the reference's own fold is the S = 1 case, which is unchanged.) */
 	uint32_t sample_split;
 	uint32_t reserved0;
 } rt_render_opts;

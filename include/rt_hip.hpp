@@ -198,6 +198,21 @@ class Bvh { // acceleration/mod.rs:44-93, resident in the HBM of `device`
 		check(rt_scene_device_count(h_, &n));
 		return n;
 	}
+	// how a multi-device Bvh moves its members' shards into devices[0], and why (rt_gather_mode; settled at construction)
+	std::pair<int, std::string> gather_info() const
+	{
+		int mode = 0;
+		char note[512] = {0};
+		check(rt_scene_gather_info(h_, &mode, note, sizeof note));
+		return {mode, std::string(note)};
+	}
+	// what rt_render_opts.sample_split = 0 resolves to for these options on this Bvh (the library's one rule)
+	uint32_t auto_sample_split(const rt_render_opts &opts) const
+	{
+		uint32_t split = 1;
+		check(rt_scene_auto_sample_split(h_, &opts, &split));
+		return split;
+	}
 	~Bvh() { rt_scene_destroy(h_); }
 	Bvh(const Bvh &) = delete;
 	Bvh &operator=(const Bvh &) = delete;

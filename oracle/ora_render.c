@@ -505,7 +505,7 @@ typedef struct render_job {
 	const rt_camera *camera;
 	rt_render_opts opts;
 	float *mean; /* W*H*3 running mean (the TUI's presentation buffer, src/main.rs:160-185) */
-	float *acc;  /* sample_split > 1: sum over finished chunks of mean_c * n_c */
+	float *acc;  /* sample_split > 1: sum over finished chunks of their sums */
 	uint32_t split;
 	uint64_t n_chunks;
 	atomic_uint_fast64_t next_chunk;
@@ -532,8 +532,8 @@ static void render_chunk(render_job *j, uint64_t chunk_i, uint64_t pass, ora_ctx
 	const uint64_t first = chunk_i * PIXEL_CHUNK_SIZE;
 	const uint64_t last = first + PIXEL_CHUNK_SIZE < pixel_num ? first + PIXEL_CHUNK_SIZE : pixel_num;
 	const uint64_t sample_index = j->opts.sample_begin + pass;
-	/* sample_split (rt_hip.h): chunk c holds passes [floor(c*spp/S), floor((c+1)*spp/S)) and is folded
-	 * with its own i = 1..n_c; with S = 1 this is the callback's `i as Float` = pass + 1 */
+	/* sample_split (rt_hip.h): chunk c holds passes [floor(c*spp/S), floor((c+1)*spp/S)); with S = 1 the fold is the
+	 * callback's running mean with `i as Float` = pass + 1 */
 	const uint64_t spp = j->opts.samples_per_pixel, S = j->split;
 	uint64_t chunk = pass * S / spp;
 	while ((chunk + 1) * spp / S <= pass)
@@ -543,7 +543,6 @@ static void render_chunk(render_job *j, uint64_t chunk_i, uint64_t pass, ora_ctx
 	const uint64_t chunk_begin = chunk * spp / S, chunk_end = (chunk + 1) * spp / S;
 	const float i_f = (float)(pass - chunk_begin + 1);
 	const bool chunk_starts = pass == chunk_begin, chunk_ends = pass + 1 == chunk_end;
-	const float n_c = (float)(chunk_end - chunk_begin);
 	uint64_t rays_shot = 0;
 	for (uint64_t pixel_i = first; pixel_i < last; ++pixel_i) {
 		const uint64_t x = pixel_i % width;
@@ -560,20 +559,28 @@ static void render_chunk(render_job *j, uint64_t chunk_i, uint64_t pass, ora_ctx
 		                     ? ora_naive_get_colour(j->scene, &ray, j->opts.max_depth, j->opts.rr_threshold, &rc, ctx)
 		                     : ora_mis_get_colour(j->scene, &ray, j->opts.max_depth, j->opts.rr_threshold, &rc, ctx);
 		rays_shot += rc;
-		/* src/main.rs:179-185: *pres += (acc - *pres) / i as Float */
 		float *pres = &j->mean[pixel_i * 3];
-		if (S > 1 && chunk_starts)
-			pres[0] = pres[1] = pres[2] = 0.0f;
-		pres[0] += (rgb.x - pres[0]) / i_f;
-		pres[1] += (rgb.y - pres[1]) / i_f;
-		pres[2] += (rgb.z - pres[2]) / i_f;
-		if (S > 1 && chunk_ends) {
-			float *a = &j->acc[pixel_i * 3];
-			for (int k = 0; k < 3; ++k)
-				a[k] = a[k] + pres[k] * n_c;
-			if (pass + 1 == spp)
+		if (S == 1) {
+			/* src/main.rs:179-185: *pres += (acc - *pres) / i as Float */
+			pres[0] += (rgb.x - pres[0]) / i_f;
+			pres[1] += (rgb.y - pres[1]) / i_f;
+			pres[2] += (rgb.z - pres[2]) / i_f;
+		} else {
+			/* sample_split S > 1 (rt_hip.h): the passes of a chunk are SUMMED in pass order, the chunk sums are summed in chunk
+			 * order and the total is divided by spp once */
+			if (chunk_starts)
+				pres[0] = pres[1] = pres[2] = 0.0f;
+			pres[0] += rgb.x;
+			pres[1] += rgb.y;
+			pres[2] += rgb.z;
+			if (chunk_ends) {
+				float *a = &j->acc[pixel_i * 3];
 				for (int k = 0; k < 3; ++k)
-					pres[k] = a[k] / (float)spp;
+					a[k] = a[k] + pres[k];
+				if (pass + 1 == spp)
+					for (int k = 0; k < 3; ++k)
+						pres[k] = a[k] / (float)spp;
+			}
 		}
 	}
 	atomic_fetch_add(&j->rays_shot, rays_shot);

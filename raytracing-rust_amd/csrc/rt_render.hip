@@ -439,10 +439,16 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		V3 c = outp;
 		if (filter && (contains_nan(c) || !is_finite_any(c))) // integrators/mod.rs:74-76, mis.rs:88-90
 			c = v3s(0.0f);
-		const float i_f = (float)(sample_local + 1u);
-		mean.x += (c.x - mean.x) / i_f; // src/main.rs:179-185
-		mean.y += (c.y - mean.y) / i_f;
-		mean.z += (c.z - mean.z) / i_f;
+		if (P.sample_split > 1u) { // (wave-uniform) a chunk of a pixel's passes: their SUM, in pass order (rt_hip.h sample_split)
+			mean.x += c.x;
+			mean.y += c.y;
+			mean.z += c.z;
+		} else {
+			const float i_f = (float)(sample_local + 1u);
+			mean.x += (c.x - mean.x) / i_f; // src/main.rs:179-185
+			mean.y += (c.y - mean.y) / i_f;
+			mean.z += (c.z - mean.z) / i_f;
+		}
 		rays_total += ray_count;
 		sample_local += 1;
 		if (sample_local == chunk_n) {
@@ -1572,8 +1578,8 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	}
 }
 
-// ---- sample_split > 1: fold the per-chunk means of every pixel, in chunk order:
-// (sum_c mean_c * n_c) / spp in f32 (the definition in rt_hip.h) ----
+// ---- sample_split > 1: add the per-chunk sums of every pixel, in chunk order, and divide by spp:
+// (sum_c sum_c) / spp in f32 (the definition in rt_hip.h) ----
 __global__ __launch_bounds__(256) void combine_chunks_kernel(const DevRenderParams P, const float *__restrict__ partial, float *__restrict__ out)
 {
 	const uint32_t wp = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1584,12 +1590,10 @@ __global__ __launch_bounds__(256) void combine_chunks_kernel(const DevRenderPara
 		return; // edge-tile padding
 	V3 acc = v3s(0.0f);
 	for (uint32_t c = 0; c < P.sample_split; ++c) {
-		const uint32_t b = (uint32_t)(((uint64_t)c * P.spp) / P.sample_split);
-		const float n_c = (float)((uint32_t)(((uint64_t)(c + 1u) * P.spp) / P.sample_split) - b);
 		const float *m = partial + 3u * ((size_t)c * P.n_work + wp);
-		acc.x = acc.x + m[0] * n_c;
-		acc.y = acc.y + m[1] * n_c;
-		acc.z = acc.z + m[2] * n_c;
+		acc.x = acc.x + m[0];
+		acc.y = acc.y + m[1];
+		acc.z = acc.z + m[2];
 	}
 	const size_t o = P.shard_layout ? (size_t)wp : (size_t)y * P.width + x;
 	out[3u * o + 0u] = acc.x / (float)P.spp;

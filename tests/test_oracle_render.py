@@ -225,8 +225,8 @@ def test_max_depth_is_a_parameter(O):
 
 
 def test_sample_split_is_a_reordering_of_the_same_samples(O):
-    """rt_render_opts.sample_split: S chunks per pixel, each folded on its own, combined in chunk order as
-    (sum mean_c * n_c) / spp.  S = 1 is the reference's strictly sequential fold (golden images); any S
+    """rt_render_opts.sample_split: S chunks per pixel, each summed on its own in pass order, the sums added in chunk order
+    and divided by spp once.  S = 1 is the reference's strictly sequential running mean (golden images); any S
     uses the same samples and streams, so the image moves only by float rounding."""
     ls = scenes.load_ssml("overshadowed")
     s = O.Scene(ls.scene); cam = O.camera_new(**ls.camera_params)
@@ -244,10 +244,10 @@ def test_sample_split_is_a_reordering_of_the_same_samples(O):
     want = np.zeros(3, np.float32)
     for (b, e) in ((0, 3), (3, 6), (6, 10)):
         m = np.zeros(3, np.float32)
-        for i, k in enumerate(range(b, e), start=1):
-            m = m + (per_pass[k] - m) / np.float32(i)
-        want = want + m * np.float32(e - b)
-    want = want / np.float32(10)
+        for k in range(b, e):
+            m = m + per_pass[k]   # a chunk's passes are summed in pass order ...
+        want = want + m           # ... the chunk sums in chunk order ...
+    want = want / np.float32(10)  # ... and the total is divided by spp once
     o = abi.default_render_opts(48, 27, 10); o.sample_split = 3
     assert np.array_equal(s.render(cam, o)[0][20, 30], want)
     o.sample_split = 11
