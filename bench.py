@@ -58,10 +58,13 @@ VALU_PLAIN_CYCLES_MEASURED = 2.5     # v_fma / v_xor / v_mov / v_cndmask (2.27 w
 VALU_HALF_RATE_CYCLES_MEASURED = 4.25  # v_mul_lo/hi_u32, v_mad_u64_u32, v_pk_*_f32
 VALU_TRANS_CYCLES_MEASURED = 8.25    # v_rcp_f32, v_sqrt_f32
 SALU_CYCLES_MEASURED = 2.15          # a scalar instruction of the same wave, interleaved 1:1 with VALU: 4.65 per pair, i.e. NOT free
-# dependent random record fetches, every lane its own chain (tests/microbench/random_fetch.hip ->
-# profiles/r01d_random_fetch_microbench.txt): 115 G/s when the set is L2-resident, 57 G/s beyond L2
-L2_FETCH_CEILING_RESIDENT = 115.0e9
+# dependent random record fetches, every lane its own chain, in the walk's real access shape -- three 16-byte pieces of a 64-byte
+# record, four waves per SIMD (tests/probes/microbench/random_fetch.hip -> profiles/r04h_random_fetch_microbench.txt): 237 G records/s
+# when the set is L2-resident per XCD (2 MB), 57 G/s from 128 MB up AND at 1 GB, beyond the Infinity Cache: past the L2s every record
+# costs one 128-byte fabric line, 57 G lines/s = 7.3 TB/s.  (Round 1's 115 / 57 were measured at 8 MB -- a blend -- and 134 MB.)
+L2_FETCH_CEILING_RESIDENT = 237.0e9
 L2_FETCH_CEILING_BEYOND = 57.0e9
+RANDOM_LINE_CEILING_GBS = L2_FETCH_CEILING_BEYOND * 128.0 / 1e9  # 7 296 GB/s of 128-byte lines over the fabric
 
 # bytes: SURVEY 8(d) algorithmic bytes per sample under REFERENCE traversal semantics, counted by
 # tests/probes/count_algorithmic_bytes.py (32 B/node test, 16 B/sphere test, 36 B/triangle test, 52 B/closest
@@ -497,8 +500,10 @@ def main():
                          "blended_ceiling_at_this_hit_rate": ceiling / 1e9 if ceiling else None,
                          "frac_of_blended_ceiling": achieved / ceiling if (achieved and ceiling) else None,
                          "lane_utilisation": counters.get("valu_lane_utilisation"),
-                         "note": "every node step is a dependent, effectively random 64-byte fetch; peak = measured dependent-random-fetch "
-                                 "rate of an L2-resident set (115 G/s), 57 G/s beyond L2 (profiles/r01d_random_fetch_microbench.txt)"})
+                         "note": "every node step is a dependent, effectively random fetch of 48 bytes of a 64-byte record; peak = the measured rate of "
+                                 "such fetches over an L2-resident set (237 G/s), 57 G/s beyond the L2s -- Infinity Cache or HBM alike: one 128-byte fabric "
+                                 "line each, 7.3 TB/s (profiles/r04h_random_fetch_microbench.txt); blended_ceiling = harmonic blend of the two at the "
+                                 "kernel's own L2 hit rate (a model: the fractions are printed unclamped)"})
         ws = None
         if world == 1 and not args.no_walk_stats:
             ws, ws_error = walk_stats(name)
@@ -524,14 +529,18 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS if achieved else None,
                          "achievable_peak": HBM_ACHIEVABLE_GBS,
                          "fabric_GBps_from_pmc": measured, "fabric_frac_of_peak": measured / HBM_PEAK_GBS if measured else None,
-                         "fabric_frac_of_achievable": measured / HBM_ACHIEVABLE_GBS if measured else None,
+                         "random_line_ceiling_GBps": RANDOM_LINE_CEILING_GBS,
+                         "fabric_frac_of_random_line_ceiling": measured / RANDOM_LINE_CEILING_GBS if measured else None,
                          "l2_hit_rate": counters.get("l2_hit_rate"),
                          "lane_utilisation": counters.get("valu_lane_utilisation"),
                          "note": "achieved = bytes the pruned walk REQUESTS (48 B/node step + 48 B/primitive test, counted live) / kernel time; "
                                  "fabric_GBps_from_pmc = what crossed the fabric (Infinity Cache + HBM, 128-byte lines) in the committed profile "
                                  "of this build: above the requested bytes because a node step uses 48 bytes of the 128-byte line it arrives in "
-                                 "(the line count, not the byte count, is what HBM serves).  fabric_frac_of_achievable is NOT the binding limit, "
-                                 "though it reads like one: eight-child nodes moved 22 % fewer lines over the fabric and the launch got 6 % slower "
+                                 "(the line count, not the byte count, is what the fabric serves).  fabric bytes are NOT HBM bytes (Infinity-Cache hits are "
+                                 "counted, MI355X_MICROARCH.md): the ceiling they are compared with is the measured rate of dependent random 128-byte line "
+                                 "fetches beyond the L2s, 57 G lines/s = 7.3 TB/s, the same from the Infinity Cache and from HBM "
+                                 "(profiles/r04h_random_fetch_microbench.txt).  Fewer lines alone do not shorten the launch: eight-child nodes moved 22 % "
+                                 "fewer lines over the fabric and the launch got 6 % slower "
                                  "(profiles/archive_r03/r04w8_mesh10m_pmc.json against r03n_mesh10m_pmc.json there; HISTORY.md): the launch follows lane-level 16-byte "
                                  "fetches and VALU instructions, HBM is the nearest roofline"})
         ab = w["bytes"]

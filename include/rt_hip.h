@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+/* 2 (round 4): rt_render_opts.sample_split = 0 means "the library picks" (rt_scene_auto_sample_split) and S > 1 adds chunk SUMS
+ * (rounds 1 - 3: 0 was the sequential fold, chunks were running means); new entry points rt_scene_auto_sample_split,
+ * rt_scene_gather_info, rt_rccl_probe, rt_selftest_division, rt_scene_get_wide_nodes_compact, rt_scene_get_leaf_boxes_compact */
+#define RT_ABI_VERSION 2u
 
 typedef enum rt_status {
 	RT_OK = 0,

@@ -5,7 +5,7 @@ sizes against the values the C compiler reports.
 """
 import ctypes as C
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_GATHER_NONE, RT_GATHER_RCCL, RT_GATHER_PEER, RT_GATHER_PEER_STAGED, RT_GATHER_SAME_DEVICE = 0, 1, 2, 3, 4
 
 RT_OK = 0
