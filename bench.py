@@ -74,6 +74,13 @@ WORKLOADS = {
                    "label": "scenes/rtweekend1.ssml", "config": "BASELINE configs[1]"},
     "overshadowed": {"width": 1920, "height": 1080, "spp": 1024, "seed": 1, "bytes": 488.42, "bound": "valu_issue",
                      "label": "scenes/overshadowed.ssml", "config": "BASELINE configs[2]"},
+    # NOT a BASELINE config: ~500 random spheres under a sampled Lerp sky (the RTIOW cover shape) -- the general spheres-only kernels
+    # (pruned walk over the wide tree, coarse schedule), i.e. what the small-scene path delivers beyond rtweekend1's two-sphere special case
+    "spheres500": {"width": 1920, "height": 1080, "spp": 256, "seed": 7, "bytes": None, "bound": "valu_issue",
+                   "label": "500 random spheres (tests/scenes.py random_spheres(500, seed=7), sky sampled at 100x100)",
+                   "config": "not a BASELINE config: the general small-scene path", "spheres": 500,
+                   "camera": {"origin": (0.0, -30.0, 6.0), "lookat": (0.0, 0.0, 0.0), "vup": (0.0, 0.0, 1.0), "fov": 50.0, "aspect_ratio": 16.0 / 9.0,
+                              "aperture": 0.0, "focus_dist": 10.0}},
     "mesh1m": {"width": 1920, "height": 1080, "spp": 256, "seed": 42, "bytes": 38990.98, "bound": "l2_request_rate",
                "label": "synthetic 1M random-triangle mesh", "config": "BASELINE configs[3] on one GPU",
                "triangles": 1000000, "extent": 10.0},
@@ -123,6 +130,10 @@ def load_workload(pkg, name):
         if "aspect" in w:
             cam["aspect_ratio"] = w["aspect"]
         return scenes.random_triangle_mesh(w["triangles"], seed=w["seed"], extent=w["extent"]), cam
+    if "spheres" in w:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes
+        return scenes.random_spheres(w["spheres"], seed=w["seed"], sampler_res=(100, 100)), dict(w["camera"])
     ls = pkg.ssml.load_file(os.path.join(ROOT, "tests", "golden", "scenes", name + ".ssml"))
     return ls.scene, ls.camera_params
 
@@ -297,7 +308,7 @@ def main():
     w = WORKLOADS[name]
     # default: a timed region of 10 s or more (80 x 125 ms for the headline workload), so that coarse telemetry sees the GPU busy
     if args.steps is None:
-        args.steps = {"rtweekend1": 80, "overshadowed": 50, "mesh1m": 6, "mesh10m": 2}[name]
+        args.steps = {"rtweekend1": 80, "overshadowed": 50, "mesh1m": 6, "mesh10m": 2, "spheres500": 20}[name]
     if args.warmup is None:
         args.warmup = 3 if w["bound"] == "valu_issue" else 1
 

@@ -176,6 +176,20 @@ RT_HD uint32_t rt_rng_below(rt_rng *r, uint32_t n)
 {
 	if (n == 0u)
 		return 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* n = 2^k (one light, or none, besides the sky: the reference's scenes): the crate's widening multiply is two shifts --
+	 * hi = v >> (32 - k), lo = v << k, zone = 2^31 - 1, so a draw is accepted iff bit (31 - k) of v is clear (rand 0.8's
+	 * sample_single rejects HALF of all draws for a power-of-two range, and a wave loops until its unluckiest lane accepts:
+	 * about seven trips, each without the two half-rate 32-bit multiplies now).  Same draws, same results. */
+	if ((n & (n - 1u)) == 0u) {
+		const uint32_t k = 31u - (uint32_t)__builtin_clz(n);
+		for (;;) {
+			const uint32_t v = rt_rng_u32(r);
+			if (((v << k) & 0x80000000u) == 0u)
+				return k == 0u ? 0u : v >> (32u - k);
+		}
+	}
+#endif
 	uint32_t lz = 0;
 	for (uint32_t m = n; (m & 0x80000000u) == 0u; m <<= 1)
 		++lz;

@@ -40,7 +40,22 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     for r in rows:
         r["Name"] = r["Name"][:120]
         wr.writerow(r)
-render = [r for r in rows if "render_kernel" in r["Name"]][0]
+# the render kernel THE BENCH LINE names (bench.py also launches the general spheres-only kernel on the headline workload, untimed
+# for `value`: its dispatches must not be mixed into the headline kernel's counters)
+def norm(name):
+    return name.replace("void ", "").split("(")[0].replace("> >", ">>").strip()
+
+
+wanted = None
+tb = read("trace_bench.json")
+if tb:
+    try:
+        wanted = json.loads([l for l in tb.splitlines() if l.startswith("{")][-1])["roofline"]["kernel"]
+    except Exception:
+        wanted = None
+render_rows = [r for r in rows if "render_kernel" in r["Name"]]
+render = ([r for r in render_rows if wanted and norm(r["Name"]) == wanted] or render_rows)[0]
+wanted = wanted or norm(render["Name"])
 
 counters = collections.OrderedDict()
 launches = {}
@@ -52,7 +67,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         ids = set()
         info = {}
         for r in csv.DictReader(open(f)):
-            if "render_kernel" in r["Kernel_Name"]:
+            if "render_kernel" in r["Kernel_Name"] and norm(r["Kernel_Name"]) == wanted:
                 per[r["Counter_Name"]] += float(r["Counter_Value"])
                 ids.add(r["Dispatch_Id"])
                 info = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
