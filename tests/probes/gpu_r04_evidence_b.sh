@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04k
 mkdir -p $O
 cd $R
-for WL in rtweekend1 overshadowed mesh1m mesh10m; do
+for WL in rtweekend1 overshadowed spheres500 mesh1m mesh10m; do
   timeout -k 10 500 python bench.py --workload $WL > $O/bench_$WL.json 2> $O/bench_$WL.err && python -c "
 import json;d=json.load(open('$O/bench_$WL.json'));r=d['roofline'];print('$WL',round(d['value'],1),'Msamples/s',round(d['ms_per_step'],2),'ms split',d['config']['sample_split'],'frac',r.get('frac'),'cpu',round(d['cpu_baseline']['value'],2))"
 done
