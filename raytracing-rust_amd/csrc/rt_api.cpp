@@ -25,13 +25,16 @@ size_t render_lds_bytes(const DevScene &S, bool sky_lds, bool scene_lds, uint32_
 uint32_t render_waves_per_simd(int feature_set, bool fine);
 uint32_t render_block_threads(int feature_set, bool fine, bool xchg = false);
 size_t render_exchange_fine_lds_bytes(uint32_t waves_per_block);
-hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg);
+uint32_t render_max_block_threads(int feature_set, bool fine, bool xchg);
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg,
+                            uint32_t block_threads = 0);
 bool render_exchange_available(int method, bool prune, bool fine, int feature_set);
 size_t render_exchange_lds_bytes(uint32_t slots);
 uint32_t render_exchange_max_slots();
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair);
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair,
+                         uint32_t block_threads = 0);
 hipError_t launch_combine(hipStream_t stream, const DevRenderParams &P, const float *partial, float *out);
 hipError_t launch_reset(hipStream_t stream, uint32_t *work_counter, unsigned long long *rays_shot, float *out, size_t n_out_floats);
 hipError_t launch_quantise(hipStream_t stream, const float *rgb, size_t n_values, float inv_gamma, uint8_t *out);
@@ -1317,7 +1320,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	    (s->feature_set == 0 && s->pair_tree && !s->feature_set_forced && !prune && !fine && s->exchange_mode != 1) ? 3 : s->feature_set;
 	bool xchg = s->exchange_mode == 1 && render_exchange_available(o->render_method, prune, fine, feature_set);
 	const bool xchg_fine = xchg && fine;
-	const uint32_t block_threads = render_block_threads(feature_set, fine, xchg_fine);
+	uint32_t block_threads = render_block_threads(feature_set, fine, xchg_fine);
 	const size_t fine_pool_bytes = xchg_fine ? render_exchange_fine_lds_bytes(block_threads / 64u) : 0;
 	// Traversal stacks: one LDS column per lane.  The worst case of a deep tree (three pending siblings per level of
 	// the wide tree) is far above what walks reach, and LDS sized for it would cost resident waves; under the fine
@@ -1346,41 +1349,84 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 		stack_cap = std::min(stack_need, s->stack_cap_override);
 	P.stack_cap = stack_cap;
 	P.stack_ovf_depth = stack_need - stack_cap;
-	size_t lds_bytes = render_lds_bytes(dev, false, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
-	if (lds_bytes > s->max_lds)
-		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
-	int blocks_per_cu = 0;
-	HIP_TRY(render_occupancy(o->render_method, prune, fine, false, feature_set, lds_bytes, &blocks_per_cu, xchg_fine));
-	if (samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024) {
-		const size_t lds_with = render_lds_bytes(dev, true, scene_lds, block_threads / 64u, stack_cap) + fine_pool_bytes;
-		int blocks_with = 0;
-		if (lds_with <= s->max_lds &&
-		    render_occupancy(o->render_method, prune, fine, true, feature_set, lds_with, &blocks_with, xchg_fine) == hipSuccess &&
-		    blocks_with >= blocks_per_cu && blocks_with >= 1) {
-			sky_lds = true;
-			lds_bytes = lds_with;
-			blocks_per_cu = blocks_with;
+	// What one workgroup size gives: resident workgroups per CU without and -- where that does not cost any -- with the sky tables in LDS
+	const bool sky_lds_possible = samplable && o->render_method == RT_METHOD_MIS && sky_bytes <= 96 * 1024;
+	struct Sizing { uint32_t block; int blocks_per_cu; bool sky; size_t lds; };
+	auto size_launch = [&](uint32_t block, Sizing &z) -> hipError_t {
+		z.block = block;
+		z.sky = false;
+		z.blocks_per_cu = 0;
+		z.lds = render_lds_bytes(dev, false, scene_lds, block / 64u, stack_cap) + fine_pool_bytes;
+		if (z.lds > s->max_lds)
+			return hipSuccess; // (does not fit: blocks_per_cu stays 0)
+		hipError_t e = render_occupancy(o->render_method, prune, fine, false, feature_set, z.lds, &z.blocks_per_cu, xchg_fine, block);
+		if (e != hipSuccess)
+			return e;
+		if (sky_lds_possible) {
+			const size_t lds_with = render_lds_bytes(dev, true, scene_lds, block / 64u, stack_cap) + fine_pool_bytes;
+			int blocks_with = 0;
+			if (lds_with <= s->max_lds &&
+			    render_occupancy(o->render_method, prune, fine, true, feature_set, lds_with, &blocks_with, xchg_fine, block) == hipSuccess &&
+			    blocks_with >= z.blocks_per_cu && blocks_with >= 1) {
+				z.sky = true;
+				z.lds = lds_with;
+				z.blocks_per_cu = blocks_with;
+			}
 		}
+		return hipSuccess;
+	};
+	Sizing Z;
+	HIP_TRY(size_launch(block_threads, Z));
+	if (Z.lds > s->max_lds)
+		return fail(RT_ERR_UNSUPPORTED, "traversal stacks exceed the LDS of one CU");
+	// Coarse spheres-only kernels (FeatPair among them) are issue-bound and use 66 - 100 VGPRs: every further wave per SIMD the
+	// registers allow is worth about 2 % (rt_render.hip RT_PAIR_WAVES).  Three 512-thread workgroups do not fit the LDS with the
+	// sky tables, two of 768 threads do: try the larger workgroup too, keep what puts most waves on a CU, at equal waves what keeps
+	// the sky tables in LDS, at equal both the smaller workgroup.  Only multiples of 256 threads: a workgroup whose waves do not
+	// divide evenly over the four SIMDs is reported as resident twice by the occupancy query, but the second one is not placed
+	// once the fuller SIMDs are out of registers (640 x 2 at 93 VGPRs: 18.8 -> 23.3 ms, 896 x 2: no gain; profiles/r04v_small_ab.log).
+	if (!fine && !xchg) {
+		for (uint32_t cand = block_threads + 256u; cand <= render_max_block_threads(feature_set, fine, false); cand += 256u) {
+			Sizing C;
+			if (size_launch(cand, C) != hipSuccess || C.blocks_per_cu < 1)
+				continue;
+			const uint32_t waves_c = (uint32_t)C.blocks_per_cu * C.block, waves_z = (uint32_t)Z.blocks_per_cu * Z.block;
+			if (waves_c > waves_z || (waves_c == waves_z && C.sky && !Z.sky))
+				Z = C;
+		}
+		block_threads = Z.block;
 	}
+	size_t lds_bytes = Z.lds;
+	int blocks_per_cu = Z.blocks_per_cu;
+	sky_lds = Z.sky;
 	P.sky_in_lds = sky_lds ? 1u : 0u;
 	if (blocks_per_cu < 1)
 		return fail(RT_ERR_HIP, "render kernel does not fit on a CU");
-	// RT_TUNE_EXCHANGE: the workgroup's pool of parked path states sits behind the stacks (rt_render.hip, XCHG) and gets
-	// the LDS that is left at this occupancy -- it never costs a resident workgroup or the sky tables their place
+	// RT_TUNE_EXCHANGE (asked for by name, off by default): the workgroup's pool of parked path states sits behind the stacks
+	// (rt_render.hip, XCHG) and gets the LDS that is left at the occupancy the EXCHANGE kernel reaches by its registers -- it never
+	// costs the sky tables their place; it can cost a resident workgroup where that kernel needs more registers than the plain one
+	// (full feature set: 141 against 125 VGPRs)
 	P.xchg_slots = 0;
 	if (xchg && !fine) {
-		const size_t share = s->max_lds / (size_t)blocks_per_cu; // max_lds is the LDS of one CU
-		uint32_t slots = render_exchange_max_slots();
-		while (slots >= 16u && lds_bytes + render_exchange_lds_bytes(slots) > share)
-			slots -= 4u;
-		int blocks_x = 0;
-		if (slots >= 16u &&
-		    render_occupancy(o->render_method, prune, fine, sky_lds, feature_set, lds_bytes + render_exchange_lds_bytes(slots), &blocks_x, true) == hipSuccess &&
-		    blocks_x >= blocks_per_cu) {
-			P.xchg_slots = slots;
-			lds_bytes += render_exchange_lds_bytes(slots);
-		} else {
+		int blocks_plain = 0;
+		if (render_occupancy(o->render_method, prune, fine, sky_lds, feature_set, lds_bytes, &blocks_plain, true) != hipSuccess || blocks_plain < 1) {
 			xchg = false;
+		} else {
+			const int target = std::min(blocks_per_cu, blocks_plain);
+			const size_t share = s->max_lds / (size_t)target; // max_lds is the LDS of one CU
+			uint32_t slots = render_exchange_max_slots();
+			while (slots >= 16u && lds_bytes + render_exchange_lds_bytes(slots) > share)
+				slots -= 4u;
+			int blocks_x = 0;
+			if (slots >= 16u &&
+			    render_occupancy(o->render_method, prune, fine, sky_lds, feature_set, lds_bytes + render_exchange_lds_bytes(slots), &blocks_x, true) == hipSuccess &&
+			    blocks_x >= target) {
+				P.xchg_slots = slots;
+				lds_bytes += render_exchange_lds_bytes(slots);
+				blocks_per_cu = target;
+			} else {
+				xchg = false;
+			}
 		}
 	}
 	uint64_t n_blocks = (uint64_t)s->n_cus * (uint64_t)blocks_per_cu;
@@ -1441,7 +1487,7 @@ int rt_render_device(rt_scene *s, const rt_camera *camera, const rt_render_opts 
 	HIP_TRY(hipEventRecord(s->ev_start, stream));
 	HIP_TRY(launch_render(o->render_method, prune, fine, sky_lds, feature_set, (uint32_t)n_blocks, lds_bytes, stream, dev, cam, P, render_target,
 	                      reinterpret_cast<unsigned long long *>(d_rays_shot), s->d_work_counter, s->d_stack_ovf, xchg,
-	                      feature_set == 3 ? &s->pair : nullptr));
+	                      feature_set == 3 ? &s->pair : nullptr, block_threads));
 	HIP_TRY(hipEventRecord(s->ev_stop, stream));
 	if (split > 1u)
 		HIP_TRY(launch_combine(stream, P, s->d_partial, d_out_rgb));

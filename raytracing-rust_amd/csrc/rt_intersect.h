@@ -331,6 +331,33 @@ __device__ __forceinline__ void make_sky_hit(const DevScene &S, Hit &h, uint32_t
 	h.out = false;
 	material = S.sky.material;
 }
+// The same for a feature set whose sky is KNOWN to carry an Emit material over a texture of the DIRECTION alone (FeatPair's
+// contract, rt_types.h): the path ends there and nothing ever reads the zeroed position / normal / error of the sky "hit", so they
+// are left as whatever the registers hold -- well-defined values the compiler need not produce (eight v_mov per shading arm of the
+// config-2 loop otherwise).  The flags and t, which control flow could look at, stay defined.  (Any other feature set may meet a
+// sky whose material scatters -- tests/test_gpu_parity.py "a lambertian as the sky's material" -- and then the zeros ARE the hit.)
+template <class F> __device__ __forceinline__ void make_sky_hit_lean(const DevScene &S, Hit &h, uint32_t &material)
+{
+	if (F::ctex || !F::known_materials) {
+		make_sky_hit(S, h, material);
+		return;
+	}
+	h.t = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_ANY_VALUE(x) asm volatile("" : "=v"(x)) // "some value": an empty statement that defines its operand, no instruction (volatile: one
+                                                   // definition per use, or the compiler shares one register and copies it)
+#else
+#define RT_ANY_VALUE(x) x = 0.0f
+#endif
+	RT_ANY_VALUE(h.point.x); RT_ANY_VALUE(h.point.y); RT_ANY_VALUE(h.point.z);
+	RT_ANY_VALUE(h.error.x); RT_ANY_VALUE(h.error.y); RT_ANY_VALUE(h.error.z);
+	RT_ANY_VALUE(h.normal.x); RT_ANY_VALUE(h.normal.y); RT_ANY_VALUE(h.normal.z);
+	RT_ANY_VALUE(h.err_dot); RT_ANY_VALUE(h.uvx); RT_ANY_VALUE(h.uvy);
+#undef RT_ANY_VALUE
+	h.has_uv = false;
+	h.out = false;
+	material = S.sky.material;
+}
 
 // ---- traversal ----
 // "while-while" walk (Aila & Laine, HPG 2009) for 64-lane wavefronts.  A lane descends through

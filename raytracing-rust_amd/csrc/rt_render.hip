@@ -108,6 +108,20 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_SPHERES_BLOCK
 #define RT_SPHERES_BLOCK 512
 #endif
+#ifndef RT_FUSE_REGIONS
+#define RT_FUSE_REGIONS(spheres_only) true // coarse schedule: which MIS kernels run a super-phase as ONE divergent region (see kFuseRegions)
+#endif
+#ifndef RT_BODY_ALWAYS
+#define RT_BODY_ALWAYS(spheres_only) true // coarse schedule: which kernels run the loop body without the `nothing to run` arm (see there)
+#endif
+#ifndef RT_SPHERES_MAX_BLOCK
+#define RT_SPHERES_MAX_BLOCK 768 // coarse spheres-only kernels (FeatPair among them): the host launches two workgroups of 512 OR 768 threads per
+                                 // CU, whichever puts more waves on it at the kernel's register count (rt_api.cpp; 66 - 100 VGPRs)
+#endif
+#ifndef RT_PAIR_WAVES
+#define RT_PAIR_WAVES 6 // the two-sphere special case (FeatPair): 75 VGPRs (MIS), 66 (naive).  Round 4, config 2, same box: 512 x 3 without the
+                        // sky tables in LDS 62.0 ms, 640 x 2 (five waves per SIMD) 62.5, 768 x 2 (six) 61.2
+#endif
 #ifndef RT_SPHERES_WAVES
 #define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to
 #endif
@@ -145,9 +159,11 @@ template <class F, bool FINE = false, bool XCHG = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
 	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? RT_FULL_FINE_WAVES : RT_FULL_WAVES)
-	                                      : (spheres_only ? RT_SPHERES_WAVES : (FINE ? RT_SIMPLE_FINE_WAVES : RT_SIMPLE_COARSE_WAVES));
+	                                      : (F::pair ? RT_PAIR_WAVES : (spheres_only ? RT_SPHERES_WAVES : (FINE ? RT_SIMPLE_FINE_WAVES : RT_SIMPLE_COARSE_WAVES)));
 	// (fine schedule with the exchange: eight waves share the pools of walk starts and walk results, one of them shades)
 	static constexpr int block = (FINE && XCHG) ? 512 : (spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256));
+	// the largest workgroup the kernel may be launched with (its __launch_bounds__); `block` is what the host starts from
+	static constexpr int max_block = (spheres_only && !FINE && !XCHG) ? RT_SPHERES_MAX_BLOCK : block;
 };
 
 #ifdef RT_STATS
@@ -218,7 +234,7 @@ typedef const RenderArgs *KArgs; // (host pass: the kernel body is only parsed)
 #endif
 
 template <int METHOD, bool PRUNE, bool FINE, bool SKY_LDS, class F, bool XCHG = false>
-__global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F, FINE, XCHG>::waves_per_simd)) void render_kernel(const RenderArgs args_by_value)
+__global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::max_block), (KernelShape<F, FINE, XCHG>::waves_per_simd)) void render_kernel(const RenderArgs args_by_value)
 {
 	extern __shared__ __align__(16) uint32_t lds[];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -586,7 +602,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 		if (prim != kNoPrim)
 			make_hit<F>(S, prim, ray, best_t, nh, nmat, PS);
 		else
-			make_sky_hit(S, nh, nmat);
+			make_sky_hit_lean<F>(S, nh, nmat);
 		// what is known of the two materials in play without reading them (rt_shade.h, kMatRead): the new hit's follows from
 		// what was hit; a path only ever continues from a material that is not a light
 		const int known_new = F::known_materials ? (prim == kNoPrim ? kMatEmit : kMatLambertian) : kMatRead;
@@ -1166,76 +1182,108 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 	// chunks of a pixel in neighbouring lanes: the image is swept once, like S = 1, the divisions are done once per claim on
 	// wave-uniform values, and a lane's own part is masks and shifts.  What a pixel's chunks return does not depend on who folds
 	// them when, so the frame is the same as under the general order.
-	auto acquire_tiles = [&]() {
+	auto acquire_coarse = [&]() {
 		const unsigned long long need = __ballot(ph == PH_NEED_PIXEL);
-		if (need == 0ull)
-			return;
 		// Serving an acquire event costs the WHOLE wave a round of scalar loads and some sixty instructions, and with short items
 		// (sample_split) an event is due in every third or fourth iteration, half of them for a single lane.  So a few needy lanes
 		// wait for company -- an idle lane costs 1/64 of an iteration -- as long as the wave has other work to vote on.
 		if (kAcquireBatch > 1u && (uint32_t)__popcll(need) < kAcquireBatch && __ballot(ph == PH_GEN || ph == PH_LIGHT) != 0ull)
 			return;
 		const KArgs k = kargs();
-		const uint32_t n = (uint32_t)__popcll(need);
+		const bool tiled = P.tile_log2_w != 0xFFFFFFFFu; // (wave-uniform) the tiled order above, or the general one (any tile size, any split)
+		// The wave-uniform part (scalar registers only) sits behind the wave-uniform tests; the lanes' part below does NOT: it is ONE
+		// divergent region, shared by the two orders, that no lane may enter.  Behind `if (need == 0) return;`, and with a region per
+		// order, the lane state of the needy lanes (pixel, chunk, running sum, phase: 15 registers) had paths round the regions on which
+		// it was untouched, and the compiler kept it in two register sets: 15 v_mov at the top and 15 at the bottom of EVERY iteration
+		// of the persistent loop (round 4).
+		uint32_t avail = 0, old_next = 0, old_xy = 0, old_pbase = 0, base = 0, log2_w = 0, log2_s = 0;
+		if (need != 0ull) {
+			const uint32_t n = (uint32_t)__popcll(need);
 #if defined(RT_STATS) && !defined(RT_STATS_NO_HIST)
-		if (lane == 0u)
-			atomicAdd(&g_hist[2][n], 1ull);
+			if (lane == 0u)
+				atomicAdd(&g_hist[2][n], 1ull);
 #endif
-		const uint32_t avail = wq_end - wq_next;
-		const uint32_t old_next = wq_next, old_xy = wq_xy, old_pbase = wq_pbase;
-		const uint32_t log2_w = k->P.tile_log2_w & 7u, log2_s = k->P.tile_log2_w >> 8, spp = k->P.spp;
-		uint32_t base = wq_end;
-		if (avail < n) { // the range runs short: claim the next 64 items
-			const int leader = __ffsll((long long)need) - 1;
-			uint32_t claimed = 0;
-			if ((int)lane == leader)
-				claimed = atomicAdd(k->work_counter, kClaim);
-			base = (uint32_t)__builtin_amdgcn_readlane((int)claimed, leader);
-			const uint32_t b = base >> 6;              // claim number
-			const uint32_t kt = b >> log2_s;           // ... lies in this shard's kt-th tile
-			const uint32_t sub = b & ((1u << log2_s) - 1u); // ... and is that tile's sub-th group of 64 / S pixels
-			const uint32_t tile = k->P.shard_index + kt * k->P.shard_count;
-			const uint32_t ty = tile / k->P.tiles_x;
-			const uint32_t tx = tile - ty * k->P.tiles_x;
-			wq_xy = (tx << log2_w) | ((ty * k->P.tile_h) << 16);
-			wq_pbase = (kt << 6) + (sub << (6u - log2_s));
+			avail = wq_end - wq_next;
+			old_next = wq_next, old_xy = wq_xy, old_pbase = wq_pbase;
+			if (tiled)
+				log2_w = k->P.tile_log2_w & 7u, log2_s = k->P.tile_log2_w >> 8;
+			base = wq_end;
+			if (avail < n) { // the range runs short: claim the next 64 items
+				const int leader = __ffsll((long long)need) - 1;
+				uint32_t claimed = 0;
+				if ((int)lane == leader)
+					claimed = atomicAdd(k->work_counter, kClaim);
+				// (readlane, not __shfl: a shuffle's result counts as divergent, and through `base` the wave's range would live in
+				// vector registers for the whole loop)
+				base = (uint32_t)__builtin_amdgcn_readlane((int)claimed, leader);
+				if (tiled) {
+					const uint32_t b = base >> 6;              // claim number
+					const uint32_t kt = b >> log2_s;           // ... lies in this shard's kt-th tile
+					const uint32_t sub = b & ((1u << log2_s) - 1u); // ... and is that tile's sub-th group of 64 / S pixels
+					const uint32_t tile = k->P.shard_index + kt * k->P.shard_count;
+					const uint32_t ty = tile / k->P.tiles_x;
+					const uint32_t tx = tile - ty * k->P.tiles_x;
+					wq_xy = (tx << log2_w) | ((ty * k->P.tile_h) << 16);
+					wq_pbase = (kt << 6) + (sub << (6u - log2_s));
+				}
+				// the leftovers go first, the rest comes from the new claim
+				wq_next = base + (n - avail);
+				wq_end = base + kClaim;
+			} else {
+				wq_next += n;
+			}
 		}
 		if (ph == PH_NEED_PIXEL) {
 			const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
 			const bool from_old = r < avail;
 			const uint32_t w = from_old ? old_next + r : base + (r - avail);
-			const uint32_t xy = from_old ? old_xy : wq_xy;
-			const uint32_t in = w & 63u;
-			// (the other single-sweep layout -- a claim = all 64 pixels of the tile for ONE chunk, claims tile-major -- measured the
-			// same to 0.3 % at every split: profiles/r03_ab_logs/r05v_split_ab.log)
-			const uint32_t wp = (from_old ? old_pbase : wq_pbase) + (in >> log2_s); // the pixel, in this shard's order
-			const uint32_t c = in & ((1u << log2_s) - 1u);                            // ... and which of its chunks
-			const uint32_t in_tile = wp & 63u;
-			px = (xy & 0xFFFFu) + (in_tile & ((1u << log2_w) - 1u));
-			py = (xy >> 16) + (in_tile >> log2_w);
-			if (w >= k->P.n_items) {
-				ph = PH_DONE;
-			} else if (px < k->P.width && py < k->P.height) {
+			const uint32_t spp = k->P.spp;
+			bool inside;
+			if (tiled) {
+				const uint32_t xy = from_old ? old_xy : wq_xy;
+				const uint32_t in = w & 63u;
+				// (the other single-sweep layout -- a claim = all 64 pixels of the tile for ONE chunk, claims tile-major -- measured the
+				// same to 0.3 % at every split: profiles/r03_ab_logs/r05v_split_ab.log)
+				const uint32_t wp = (from_old ? old_pbase : wq_pbase) + (in >> log2_s); // the pixel, in this shard's order
+				const uint32_t c = in & ((1u << log2_s) - 1u);                            // ... and which of its chunks
+				const uint32_t in_tile = wp & 63u;
+				px = (xy & 0xFFFFu) + (in_tile & ((1u << log2_w) - 1u));
+				py = (xy >> 16) + (in_tile >> log2_w);
+				inside = px < k->P.width && py < k->P.height;
 				pixel_index = py * k->P.width + px;
 				chunk_begin = (uint32_t)(((uint64_t)c * spp) >> log2_s); // = c * spp / S (rt_hip.h sample_split)
 				chunk_n = (uint32_t)(((uint64_t)(c + 1u) * spp) >> log2_s) - chunk_begin;
-				// chunk means go to the partial buffer chunk-major (combine_chunks_kernel); whole pixels to the frame or the packed shard
+				// chunk sums go to the partial buffer chunk-major (combine_chunks_kernel); whole pixels to the frame or the packed shard
 				out_index = log2_s != 0u ? c * k->P.n_work + wp : (k->P.shard_layout ? wp : pixel_index);
+			} else {
+				const uint32_t split = k->P.sample_split, n_work = k->P.n_work;
+				inside = work_to_pixel(P, split > 1u ? w % n_work : w, px, py);
+				pixel_index = py * k->P.width + px;
+				if (split > 1u) {
+					// sample_split (rt_hip.h): this item is chunk c of its pixel; its sum goes to the
+					// partial buffer (chunk-major) and combine_chunks_kernel folds the chunks in order
+					const uint32_t c = w / n_work;
+					chunk_begin = (uint32_t)(((uint64_t)c * spp) / split);
+					chunk_n = (uint32_t)(((uint64_t)(c + 1u) * spp) / split) - chunk_begin;
+					out_index = w;
+				} else {
+					chunk_begin = 0u;
+					chunk_n = spp;
+					out_index = k->P.shard_layout ? w : pixel_index;
+				}
+			}
+			if (w >= k->P.n_items) {
+				ph = PH_DONE;
+			} else if (inside) {
 				sample_local = 0;
 				mean = v3s(0.0f);
 				ph = PH_GEN;
 			} // else: padding of an edge tile; ask again next iteration
 		}
-		if (avail < n) { // the leftovers went first, the rest came from the new claim
-			wq_next = base + (n - avail);
-			wq_end = base + kClaim;
-		} else {
-			wq_next += n;
-		}
 	};
 	auto acquire = [&]() {
-	if (!FINE && P.tile_log2_w != 0xFFFFFFFFu) { // (wave-uniform; the fine kernels measured 1.5 % slower with it on 1 M triangles, r05p)
-		acquire_tiles();
+	if constexpr (!FINE) { // (the fine kernels keep the general order below: 1.5 % slower with the tiled one on 1 M triangles, r05p)
+		acquire_coarse();
 		return;
 	}
 	// ---- work acquisition.  Lanes that ran out of samples are served from a wave-private range of
@@ -1255,6 +1303,9 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				uint32_t claimed = 0;
 				if ((int)lane == leader)
 					claimed = atomicAdd(k->work_counter, kClaim);
+				// (fine schedule only since round 4.  A shuffle's result counts as divergent, so the wave's range [wq_next, wq_end) lives
+				// in vector registers here; with readlane, as in acquire_coarse, it moves to scalar ones -- and the two mesh workloads
+				// get 0.8 % / 0.7 % SLOWER, same box, profiles/r04v_mesh_ab.log: the fine kernels are short of scalar registers, not vector ones)
 				base = __shfl(claimed, leader);
 			}
 			if (ph == PH_NEED_PIXEL) {
@@ -1416,14 +1467,27 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 			// and both arms of SHADE run inside the super-phase that started them)
 			const uint32_t n_trace = (METHOD == 1 && RT_PQ_SPLIT) ? (uint32_t)__popcll(__ballot(ph == PH_GEN))
 			                                                      : (uint32_t)__popcll(__ballot(ph == PH_GEN || ph == PH_NODE || ph == PH_LEAF || ph == PH_SHADE));
-			if (n_light + n_trace != 0u) {
+			// Nothing to run (n_light + n_trace == 0): lanes waiting for a pixel (only edge-tile padding was handed out) ask again;
+			// otherwise the wave is done.  kBodyAlways: the body below is NOT skipped in that case -- it finds no lane in any of its
+			// phases -- because an `else` arm through which the lane state passes untouched makes the compiler keep that state in
+			// two register sets: 25 v_mov at the top of every iteration, 26 - 32 at its bottom, and 101 instead of 76 VGPRs for the
+			// config-2 kernel (round 4: 66.3 -> 62.0 ms, same box; profiles/r04q_loop_else_ab.log).  The simple / full variants, which
+			// keep one divergent region per step (kFuseRegions below), get SLOWER that way (config 3: 121.3 -> 123.5 ms): they keep the arm.
+			constexpr bool kBodyAlways = RT_BODY_ALWAYS(KernelShape<F>::spheres_only);
+			if (kBodyAlways) {
+				alive = (n_light + n_trace != 0u) || __ballot(ph == PH_NEED_PIXEL) != 0ull;
+				if (XCHG && METHOD == 1 && !alive) // parked work left?  (a later push comes from a wave that is still alive and will drain it itself)
+					alive = __hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
+					        __hip_atomic_load(&pool[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+			}
+			if (kBodyAlways || n_light + n_trace != 0u) {
 				const bool run_light = (METHOD == 1) && (n_light >= kLightPhaseThreshold || n_trace == 0u || (kStarveLimit != 0u && waited >= kStarveLimit));
 				waited = run_light ? 0u : waited + n_light;
 	#ifdef RT_STATS
 				if (lane == 0u) {
 					if (!run_light) {
 						st_iters[0] += 1; st_active[0] += n_trace;
-						st_hist[(n_trace - 1u) >> 3] += 1; // PRIMARY iterations by the lanes that take part, in eighths of a wave
+						st_hist[((n_trace ? n_trace : 1u) - 1u) >> 3] += 1; // PRIMARY iterations by the lanes that take part, in eighths of a wave
 #ifndef RT_STATS_NO_HIST // (three global atomics per iteration: left out when the section clocks are what is wanted)
 						atomicAdd(&g_hist[0][n_trace], 1ull);
 						atomicAdd(&g_hist[1][n_light], 1ull);
@@ -1442,7 +1506,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				// sit the phase out are merged back once, not after every step: fewer copies of path state) for the spheres-only
 				// kernels: config 2 28.46 -> 28.02 ms at 256 spp, same box, three rounds.  The simple / full variants keep one region
 				// per step: fused, config 3 measured 42.3 -> 43.3 ms (their spilled registers move into the longer region).
-				constexpr bool kFuseRegions = METHOD == 1 && RT_PQ_SPLIT && KernelShape<F>::spheres_only;
+				constexpr bool kFuseRegions = METHOD == 1 && RT_PQ_SPLIT && RT_FUSE_REGIONS(KernelShape<F>::spheres_only);
 				bool run_q = run_light;
 				if (!run_light) {
 					if (kFuseRegions) {
@@ -1537,7 +1601,6 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::block), (KernelShape<F
 				}
 	#endif
 			} else {
-				// nothing to run: lanes waiting for a pixel (only edge-tile padding was handed out) ask again; otherwise the wave is done
 				alive = __ballot(ph == PH_NEED_PIXEL) != 0ull;
 				if (XCHG && METHOD == 1) // parked work left?  (a later push comes from a wave that is still alive and will drain it itself)
 					alive = alive || __hip_atomic_load(&pool[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
@@ -2059,17 +2122,32 @@ uint32_t render_block_threads(int feature_set, bool fine, bool xchg)
 {
 	if (fine && xchg)
 		return 512u; // KernelShape<F, true, true>::block
-	if (feature_set == 0 || feature_set == 3)
+	if (feature_set == 3)
+		return (uint32_t)KernelShape<FeatPair>::block;
+	if (feature_set == 0)
 		return (uint32_t)KernelShape<Feat<false, false, false, false>>::block;
 	if (feature_set == 1)
 		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::block : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::block;
 	return 256u;
 }
 
+uint32_t render_max_block_threads(int feature_set, bool fine, bool xchg)
+{
+	if (fine || xchg)
+		return render_block_threads(feature_set, fine, xchg);
+	if (feature_set == 3)
+		return (uint32_t)KernelShape<FeatPair>::max_block;
+	if (feature_set == 0)
+		return (uint32_t)KernelShape<Feat<false, false, false, false>>::max_block;
+	return render_block_threads(feature_set, fine, xchg);
+}
+
 // waves per SIMD the kernel's register budget is declared for (its __launch_bounds__)
 uint32_t render_waves_per_simd(int feature_set, bool fine)
 {
-	if (feature_set == 0 || feature_set == 3)
+	if (feature_set == 3)
+		return (uint32_t)KernelShape<FeatPair>::waves_per_simd;
+	if (feature_set == 0)
 		return fine ? (uint32_t)KernelShape<Feat<false, false, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<false, false, false, false>, false>::waves_per_simd;
 	if (feature_set == 1)
 		return fine ? (uint32_t)KernelShape<Feat<true, true, false, false>, true>::waves_per_simd : (uint32_t)KernelShape<Feat<true, true, false, false>, false>::waves_per_simd;
@@ -2165,7 +2243,8 @@ uint32_t render_exchange_max_slots() { return kXchgMaxSlots; }
 // ... and of the two record pools of the fine schedule (+ state words, + one scratch row per wave)
 size_t render_exchange_fine_lds_bytes(uint32_t waves_per_block) { return (size_t)(4u + kXchgFineHdr + waves_per_block * 64u + 2u * kXchgFineSlots * kXchgRecWords) * sizeof(uint32_t); }
 
-hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg)
+hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int feature_set, size_t lds_bytes, int *blocks_per_cu, bool xchg,
+                            uint32_t block_threads)
 {
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
@@ -2173,12 +2252,13 @@ hipError_t render_occupancy(int method, bool prune, bool fine, bool sky_lds, int
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if (e != hipSuccess)
 		return e;
-	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, render_block_threads(feature_set, fine, xchg), lds_bytes);
+	return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, block_threads ? block_threads : render_block_threads(feature_set, fine, xchg), lds_bytes);
 }
 
 hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int feature_set, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream,
                          const DevScene &S, const DevCamera &cam, const DevRenderParams &P, float *out,
-                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair)
+                         unsigned long long *rays_shot, uint32_t *work_counter, uint32_t *stack_ovf, bool xchg, const DevPairScene *pair,
+                         uint32_t block_threads)
 {
 	render_fn fn = pick_render(method, prune, fine, sky_lds, feature_set, xchg);
 	if (!fn)
@@ -2192,7 +2272,7 @@ hipError_t launch_render(int method, bool prune, bool fine, bool sky_lds, int fe
 	A.work_counter = work_counter;
 	A.stack_ovf = stack_ovf;
 	A.pair = pair ? *pair : DevPairScene{};
-	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, A);
+	hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(block_threads ? block_threads : render_block_threads(feature_set, fine, xchg)), lds_bytes, stream, A);
 	return hipGetLastError();
 }
 

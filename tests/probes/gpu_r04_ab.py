@@ -15,4 +15,4 @@ for name in (sys.argv[1:] or ["rtweekend1", "overshadowed"]):
         img, rays = g.render(cam, o)
         ms.append(g.last_kernel_ms()[0])
     ms.sort()
-    print(f"{name}: best {ms[0]:.2f} ms  median {ms[len(ms)//2]:.2f} ms  split {g.last_launch_info()['sample_split']}  rays {rays}  checksum {float(img.astype('float64').sum()):.9e}", flush=True)
+    print(f"{name}: best {ms[0]:.2f} ms  median {ms[len(ms)//2]:.2f} ms  split {g.last_launch_info()['sample_split']}  block {g.last_launch_info()['block_threads']} x {g.last_launch_info()['blocks_per_cu']}/CU  rays {rays}  checksum {float(img.astype('float64').sum()):.9e}", flush=True)

@@ -58,6 +58,11 @@ def test_headline_kernels_hold_their_budgets(built_table):
     # the kernel BASELINE config 2 itself runs (rtweekend1's tree is one node over two single-sphere leaves: rt_types.h FeatPair,
     # the general walk not compiled in, material types known from what was hit, the scene itself read from the kernel
     # arguments once per super-phase): no spilled register of either kind, no scratch
+    # Round 4: at most 80 VGPRs = SIX waves per SIMD (two workgroups of 768 threads per CU, rt_render.hip RT_PAIR_BLOCK) since the
+    # persistent loop stopped keeping the lane state in two register sets (101 VGPRs before); one loop-invariant 64-bit scalar
+    # may sit in two lanes of a VGPR (two v_readlane per iteration), nothing else.
     pair = built_table["void rt::render_kernel<1, false, false, true, rt::FeatPair, false>"]
-    assert pair["waves_per_simd_by_registers"] >= 4
-    assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] == 0
+    assert pair["waves_per_simd_by_registers"] >= 6
+    assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] <= 2
+    # config 3's kernel: no spilled VGPR (round 4)
+    assert simple["vgpr_spill_count"] == 0 and simple["private_segment_fixed_size"] == 0
