@@ -1412,6 +1412,10 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::max_block), (KernelSha
 				st_mark = now_;
 			}
 #endif
+			// (The arms stay an else-if chain.  The chain's join costs about 135 v_mov per iteration -- every arm leaves the lane state
+			// where it suited that arm -- and written as a SEQUENCE of guarded regions, the form that freed the coarse loop of its
+			// copies, the fine MIS kernel has 715 instead of 1010 v_mov but spills 71 VGPRs: 1 M triangles 947 -> 1 183 ms, 10 M
+			// 992 -> 1 455 ms, same box, profiles/r04x_fine_sequence_ab.log)
 			if (run == PH_NODE) {
 				// a few node steps per vote: a walk is tens to hundreds of them and the vote is not free
 #pragma unroll 1

@@ -2,8 +2,9 @@
 # round 4 evidence, part B: the bench lines of the four workloads on the final build (default flags = what the driver's tiers do
 # not pass), the headline with the driver's flags, the general-kernel probe, and the multi-rank / multi-device rehearsals on one GPU
 set -o pipefail
+TAG=${TAG:-r04z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r04k
+O=$R/gpurun_out/${TAG}
 mkdir -p $O
 cd $R
 for WL in rtweekend1 overshadowed spheres500 mesh1m mesh10m; do
