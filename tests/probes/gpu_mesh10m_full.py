@@ -2,7 +2,8 @@
 rank 0's 1/8 tile shard in one render (about 80 s of GPU), with the CPU oracle rendering six of that shard's tiles at the same
 depth and the pixels compared bit for bit; and SURVEY 8(d)'s algorithmic bytes per sample for this workload, counted by the
 oracle under reference traversal semantics on a sparse tile subset.  Writes gpurun_out/<tag>_mesh10m_full.json.
-    python tests/probes/gpu_mesh10m_full.py <tag> [spp] [sample_split]     (the oracle renders its tiles at the same split)"""
+    python tests/probes/gpu_mesh10m_full.py <tag> [spp] [sample_split]     (the oracle renders its tiles at the same split;
+                                                                            0 = the library's automatic split, resolved first)"""
 import importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,6 +27,9 @@ print(f"product: BVH + upload {time.time() - t0:.1f} s", flush=True)
 cam = hb.camera_new(**cam_params)
 opts = bench.workload_opts(abi, name, spp)          # shard 0 of 8, frame layout
 opts.output_layout = abi.RT_LAYOUT_SHARD
+if split == 0:  # the library's automatic choice (what bench.py runs), resolved here because the oracle takes explicit splits only
+    split = g.auto_sample_split(opts)
+    print(f"automatic sample_split for this launch: {split}", flush=True)
 opts.sample_split = split
 t0 = time.time()
 shard, rays = g.render(cam, opts)

@@ -94,7 +94,13 @@ int main(int argc, char **argv)
 	unsigned *d_out = nullptr;
 	if (hipMalloc(&d_out, 256 * 8 * 256 * sizeof(unsigned)) != hipSuccess) { std::printf("hipMalloc failed\n"); return 1; }
 	if (hipMalloc(&d_stamps, 256 * 8 * 4 * 2 * sizeof(unsigned long long)) != hipSuccess) { std::printf("hipMalloc failed\n"); return 1; }
-	for (int w : {1, 2, 4, 8}) {
+	std::vector<int> ws = {1, 2, 4, 8}; // or the waves per SIMD named on the command line (round 4: 5 6, for the six-wave config-2 kernel)
+	if (argc > 1) {
+		ws.clear();
+		for (int i = 1; i < argc; ++i)
+			ws.push_back(std::atoi(argv[i]));
+	}
+	for (int w : ws) {
 		run<0>("v_fma_f32", w, d_out, clock_ghz);
 		run<12>("v_fma_f32, ONE dependent chain", w, d_out, clock_ghz);
 		run<5>("v_xor_b32", w, d_out, clock_ghz);
