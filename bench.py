@@ -58,6 +58,9 @@ VALU_PLAIN_CYCLES_MEASURED = 2.5     # v_fma / v_xor / v_mov / v_cndmask (2.27 w
 VALU_HALF_RATE_CYCLES_MEASURED = 4.25  # v_mul_lo/hi_u32, v_mad_u64_u32, v_pk_*_f32
 VALU_TRANS_CYCLES_MEASURED = 8.25    # v_rcp_f32, v_sqrt_f32
 SALU_CYCLES_MEASURED = 2.15          # a scalar instruction of the same wave, interleaved 1:1 with VALU: 4.65 per pair, i.e. NOT free
+# ... and with other wave counts (wall-clock x the clock the waves read; profiles/r04_valu_issue.txt for 8, r04z_valu_issue_w5_w6.txt
+# for 5 and 6 -- the config-2 kernel runs six waves per SIMD since round 4): (plain, half-rate, transcendental, scalar)
+ISSUE_CYCLES_BY_WAVES = {4: (2.5, 4.25, 8.25, 2.15), 5: (2.4, 4.2, 8.1, 2.05), 6: (2.36, 4.03, 7.85, 1.96), 8: (2.27, 4.1, 8.1, 2.0)}
 # dependent random record fetches, every lane its own chain, in the walk's real access shape -- three 16-byte pieces of a 64-byte
 # record, four waves per SIMD (tests/probes/microbench/random_fetch.hip -> profiles/r04h_random_fetch_microbench.txt): 237 G records/s
 # when the set is L2-resident per XCD (2 MB), 57 G/s from 128 MB up AND at 1 GB, beyond the Infinity Cache: past the L2s every record
@@ -486,21 +489,25 @@ def main():
             # of the same waves for about 2.15 (v_fma + s_alu interleaved 1:1: 4.65 cycles per pair).  `issue_model` adds that up for
             # this kernel: dynamic VALU and SALU counts (PMC) x those costs, the VALU mix from the static census of the binary
             # (profiles/valu_census.json; cold paths included, so an estimate), against the SIMD cycles the launch had.
-            mix = roof.get("valu_census_issue_cycles_static_mix")
+            waves = int(launch.get("waves_per_simd") or 4)
+            c_plain, c_half, c_trans, c_salu = ISSUE_CYCLES_BY_WAVES.get(waves, ISSUE_CYCLES_BY_WAVES[4 if waves < 4 else 8])
+            mix = roof.get("valu_census_issue_cycles_static_mix")  # (the census prices the mix at four waves' costs: rescaled by the plain cost)
+            if mix:
+                mix = mix * c_plain / VALU_PLAIN_CYCLES_MEASURED
             sps = counters.get("salu_wave_instructions_per_sample")
             clock = (counters.get("effective_clock_ghz") or CLOCK_HZ / 1e9) * 1e9
             have = SIMDS * clock * k_s
-            need_valu = vps * launch_samples * (mix or VALU_PLAIN_CYCLES_MEASURED) if vps else None
-            need_salu = sps * launch_samples * SALU_CYCLES_MEASURED if sps else None
+            need_valu = vps * launch_samples * (mix or c_plain) if vps else None
+            need_salu = sps * launch_samples * c_salu if sps else None
             roof["issue_model"] = {
-                "cycles": {"plain_valu": VALU_PLAIN_CYCLES_MEASURED, "half_rate_valu": VALU_HALF_RATE_CYCLES_MEASURED, "transcendental": VALU_TRANS_CYCLES_MEASURED,
-                           "salu": SALU_CYCLES_MEASURED, "valu_static_mix": mix},
+                "waves_per_simd": waves,
+                "cycles": {"plain_valu": c_plain, "half_rate_valu": c_half, "transcendental": c_trans, "salu": c_salu, "valu_static_mix": mix},
                 "salu_wave_instructions_per_sample": sps,
                 "effective_clock_ghz_when_profiled": counters.get("effective_clock_ghz"),
-                "frac_of_plain_valu_ceiling": achieved / (VALU_ISSUE_PEAK * 2.0 / VALU_PLAIN_CYCLES_MEASURED) if achieved else None,
+                "frac_of_plain_valu_ceiling": achieved / (VALU_ISSUE_PEAK * 2.0 / c_plain) if achieved else None,
                 "simd_cycles_needed_over_available_valu_only": need_valu / have if need_valu else None,
                 "simd_cycles_needed_over_available_valu_plus_salu": (need_valu + need_salu) / have if (need_valu and need_salu) else None,
-                "source": "profiles/r04_valu_issue.txt + profiles/valu_census.json + the PMC profile named in counters_source",
+                "source": "profiles/r04_valu_issue.txt, r04z_valu_issue_w5_w6.txt + profiles/valu_census.json + the PMC profile named in counters_source",
                 "note": "a value near 1 means the SIMDs' instruction issue is what the launch waits for: only fewer, or cheaper, instructions help"}
         elif w["bound"] == "l2_request_rate":
             rps = counters.get("l2_read_requests_per_sample")
