@@ -90,8 +90,10 @@ constexpr uint32_t kDrainLanesHeavy = RT_DRAIN_LANES_HEAVY; // ... the same for 
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_FULL_WAVES
-#define RT_FULL_WAVES 3 // waves per SIMD of the full-feature variants under the coarse schedule (a few dozen spilled
-                        // registers, still faster than 2: all_materials naive 131 -> 109 ms, MIS 292 -> 275 ms); fine keeps 2
+#define RT_FULL_WAVES 5 // waves per SIMD of the full-feature variants under the coarse schedule.  Round 2: 3 (a few dozen spilled
+                        // registers, still faster than 2).  Round 4: the kernels need 119 - 125 VGPRs unconstrained (four 256-thread
+                        // workgroups per CU); at a budget of 96 = five: all_materials naive 18.75 -> 17.36 ms, MIS 36.1 -> 36.5 (noise),
+                        // same box (profiles/r04ae_small_ab.log)
 #endif
 #ifndef RT_FULL_FINE_WAVES
 #define RT_FULL_FINE_WAVES 4 // full-feature variants under the fine schedule (200 k triangles + glass and GGX spheres:
@@ -102,8 +104,15 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
                                // 100 k triangles naive 28.9 -> 25.2 ms, MIS 50.9 -> 48.8; 1 M: 37.7 -> 35.6, 62.6 -> 61.2
 #endif
 #ifndef RT_SIMPLE_COARSE_WAVES
-#define RT_SIMPLE_COARSE_WAVES 4 // simple (triangles + lights) variants under the coarse schedule: 128 VGPRs with 20-40 spilled
-                                 // registers beat 168 VGPRs at 3 waves (overshadowed MIS 212 -> 196 ms, 1 000 triangles 43 -> 33 ms)
+#define RT_SIMPLE_COARSE_WAVES 5 // simple (triangles + lights) variants under the coarse schedule.  Round 2: 128 VGPRs with 20-40 spilled
+                                 // registers beat 168 VGPRs at 3 waves (overshadowed MIS 212 -> 196 ms).  Round 4: the kernels need 93 - 121
+                                 // VGPRs unconstrained; at a budget of 96 (FIVE waves per SIMD: five 256-thread workgroups per CU, one wave
+                                 // per SIMD each -- the sky tables then stay in global memory) the config-3 kernel spills 39 registers and
+                                 // is still 4.5 % faster, 114.4 -> 109.3 ms, same box (profiles/r04ad_simple_five_waves_ab.log); at 80 (six
+                                 // waves, 124 spilled) 8.6 % slower (r04ab).  An extra wave hides more latency than the spills add.
+#endif
+#ifndef RT_SIMPLE_COARSE_BLOCK
+#define RT_SIMPLE_COARSE_BLOCK 256
 #endif
 #ifndef RT_SPHERES_BLOCK
 #define RT_SPHERES_BLOCK 512
@@ -123,7 +132,15 @@ constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
                         // sky tables in LDS 62.0 ms, 640 x 2 (five waves per SIMD) 62.5, 768 x 2 (six) 61.2
 #endif
 #ifndef RT_SPHERES_WAVES
-#define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to
+#define RT_SPHERES_WAVES 4 // waves per SIMD the spheres-only variants are register-limited to under the FINE schedule (119 - 128 VGPRs)
+#endif
+#ifndef RT_SPHERES_COARSE_WAVES
+// ... and under the coarse schedule: a budget of 80 VGPRs = SIX waves per SIMD.  The exhaustive MIS kernel needs 93 without the
+// limit and spills 6 registers (28 bytes of scratch) with it: config 2 through the general kernel 69.0 -> 62.1 ms, same box
+// (profiles/r04aa_spheres_six_waves_ab.log) -- two more waves per SIMD are worth 10 % to an issue-bound kernel, far more than the
+// issue microbenchmark's 2.5 -> 2.36 cycles: they also hide each other's latencies.  (The config-3 kernel, 121 VGPRs, spills 124
+// at that budget: 114.4 -> 124.2 ms, profiles/r04ab_simple_six_waves_ab.log; at 96, five waves, it gains: RT_SIMPLE_COARSE_WAVES.)
+#define RT_SPHERES_COARSE_WAVES 6
 #endif
 
 __device__ __forceinline__ float power_heuristic(float pdf_a, float pdf_b) // rt_core/src/lib.rs:36-40
@@ -158,12 +175,14 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 template <class F, bool FINE = false, bool XCHG = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
-	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? RT_FULL_FINE_WAVES : RT_FULL_WAVES)
-	                                      : (F::pair ? RT_PAIR_WAVES : (spheres_only ? RT_SPHERES_WAVES : (FINE ? RT_SIMPLE_FINE_WAVES : RT_SIMPLE_COARSE_WAVES)));
+	// (the exchange variants -- opt-in, measured slower, kept for their tests -- keep the register budgets they were built and measured with)
+	static constexpr int waves_per_simd = (F::cmat || F::ctex) ? (FINE ? RT_FULL_FINE_WAVES : (XCHG ? 3 : RT_FULL_WAVES))
+	                                      : (F::pair ? RT_PAIR_WAVES : (spheres_only ? ((FINE || XCHG) ? RT_SPHERES_WAVES : RT_SPHERES_COARSE_WAVES)
+	                                                                                 : (FINE ? RT_SIMPLE_FINE_WAVES : (XCHG ? 4 : RT_SIMPLE_COARSE_WAVES))));
 	// (fine schedule with the exchange: eight waves share the pools of walk starts and walk results, one of them shades)
-	static constexpr int block = (FINE && XCHG) ? 512 : (spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE && RT_SIMPLE_COARSE_WAVES == 4) ? 512 : 256));
+	static constexpr int block = (FINE && XCHG) ? 512 : (spheres_only ? RT_SPHERES_BLOCK : ((simple && !FINE) ? RT_SIMPLE_COARSE_BLOCK : 256));
 	// the largest workgroup the kernel may be launched with (its __launch_bounds__); `block` is what the host starts from
-	static constexpr int max_block = (spheres_only && !FINE && !XCHG) ? RT_SPHERES_MAX_BLOCK : block;
+	static constexpr int max_block = ((spheres_only || simple) && !FINE && !XCHG && block == 512) ? RT_SPHERES_MAX_BLOCK : block;
 };
 
 #ifdef RT_STATS
@@ -2143,6 +2162,8 @@ uint32_t render_max_block_threads(int feature_set, bool fine, bool xchg)
 		return (uint32_t)KernelShape<FeatPair>::max_block;
 	if (feature_set == 0)
 		return (uint32_t)KernelShape<Feat<false, false, false, false>>::max_block;
+	if (feature_set == 1)
+		return (uint32_t)KernelShape<Feat<true, true, false, false>>::max_block;
 	return render_block_threads(feature_set, fine, xchg);
 }
 

@@ -44,25 +44,25 @@ def test_default_kernels_match_the_committed_table(built_table):
 
 
 def test_headline_kernels_hold_their_budgets(built_table):
-    """the kernels of BASELINE configs 2 and 3 (coarse schedule, MIS, sky tables in LDS): 4 waves per SIMD and, since the
-    kernel arguments are read where they are used (RenderArgs in rt_render.hip), no SGPR spills to speak of and next to no
-    scratch in the spheres-only kernel"""
+    """the kernels of BASELINE configs 2 and 3 and the general spheres-only kernel (coarse schedule, MIS).  Round 4 found that one
+    more wave per SIMD is worth 4 - 10 % to these issue-bound kernels, more than a few dozen spilled registers cost: the register
+    budgets are declared for SIX waves (spheres-only: 80 VGPRs) and FIVE (triangles + lights: 96), measured against the unconstrained
+    kernels on one box (rt_render.hip RT_SPHERES_COARSE_WAVES / RT_SIMPLE_COARSE_WAVES)"""
     spheres = built_table["void rt::render_kernel<1, false, false, true, rt::Feat<false, false, false, false>, false>"]
     simple = built_table["void rt::render_kernel<1, false, false, true, rt::Feat<true, true, false, false>, false>"]
-    assert spheres["waves_per_simd_by_registers"] >= 4 and simple["waves_per_simd_by_registers"] >= 4
-    # (running BOUNCE in the iteration whose PRIMARY filled it parks 13 loop-invariant / rarely used registers in 40 bytes of
-    # scratch and is still 1 % faster than the spill-free loop, same-box A/B gpurun_out/r03r: that much is allowed, no more)
-    # (15 with the material handles of rt_types.h, same 40 bytes of scratch)
-    assert spheres["private_segment_fixed_size"] <= 48 and spheres["vgpr_spill_count"] <= 16
+    simple_global_sky = built_table["void rt::render_kernel<1, false, false, false, rt::Feat<true, true, false, false>, false>"]  # what config 3 launches
+    assert spheres["waves_per_simd_by_registers"] >= 6
+    assert simple["waves_per_simd_by_registers"] >= 5 and simple_global_sky["waves_per_simd_by_registers"] >= 5
+    # what those budgets cost, as measured: anything above is a regression of the code, not of the budget
+    assert spheres["private_segment_fixed_size"] <= 32 and spheres["vgpr_spill_count"] <= 8
     assert spheres["sgpr_spill_count"] <= 24
+    assert simple["vgpr_spill_count"] <= 44 and simple_global_sky["vgpr_spill_count"] <= 24
+    assert simple["private_segment_fixed_size"] <= 100 and simple_global_sky["private_segment_fixed_size"] <= 72
     # the kernel BASELINE config 2 itself runs (rtweekend1's tree is one node over two single-sphere leaves: rt_types.h FeatPair,
     # the general walk not compiled in, material types known from what was hit, the scene itself read from the kernel
-    # arguments once per super-phase): no spilled register of either kind, no scratch
-    # Round 4: at most 80 VGPRs = SIX waves per SIMD (two workgroups of 768 threads per CU, rt_render.hip RT_PAIR_BLOCK) since the
+    # arguments once per super-phase): at most 80 VGPRs = six waves per SIMD WITHOUT a spilled vector register, no scratch, since the
     # persistent loop stopped keeping the lane state in two register sets (101 VGPRs before); one loop-invariant 64-bit scalar
     # may sit in two lanes of a VGPR (two v_readlane per iteration), nothing else.
     pair = built_table["void rt::render_kernel<1, false, false, true, rt::FeatPair, false>"]
     assert pair["waves_per_simd_by_registers"] >= 6
     assert pair["private_segment_fixed_size"] == 0 and pair["vgpr_spill_count"] == 0 and pair["sgpr_spill_count"] <= 2
-    # config 3's kernel: no spilled VGPR (round 4)
-    assert simple["vgpr_spill_count"] == 0 and simple["private_segment_fixed_size"] == 0
