@@ -167,11 +167,12 @@ __device__ __forceinline__ bool work_to_pixel(const DevRenderParams &P, uint32_t
 	return x < P.width && y < P.height;
 }
 
-// Workgroup size and register budget per feature set.  Spheres-only kernels fit 128 VGPRs = 4 waves per
-// SIMD, but three 256-thread workgroups with a 41 KB sky table each are all the LDS of a CU holds, so
-// they run as two 512-thread workgroups (16 waves per CU, 152 -> 144 ms on rtweekend1); so do the simple
-// variants under the coarse schedule.  Fine-schedule kernels keep 256 threads (their LDS goes to the
-// traversal stacks) at 4 waves per SIMD, full-feature coarse kernels 3.
+// Workgroup size and register budget per feature set (the macros above say what each was measured against).  Coarse schedule:
+// spheres-only kernels (FeatPair among them) are declared for six waves per SIMD and start from 512 threads -- the host launches
+// two workgroups of 512 or 768 per CU, whichever puts more waves on it (rt_api.cpp), 768 x 2 keeps the 54 KB sky tables in LDS;
+// triangles + lights and full-feature kernels are declared for five and run as five 256-thread workgroups (one wave per SIMD each;
+// the sky tables then stay in global memory).  Fine-schedule kernels keep 256 threads (their LDS goes to the traversal stacks) at
+// four waves per SIMD.
 template <class F, bool FINE = false, bool XCHG = false> struct KernelShape {
 	static constexpr bool spheres_only = !(F::tri || F::lights || F::cmat || F::ctex);
 	static constexpr bool simple = !spheres_only && !(F::cmat || F::ctex);
