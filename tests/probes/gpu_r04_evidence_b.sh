@@ -20,3 +20,4 @@ RT_BENCH_REHEARSAL=1 timeout -k 10 300 python bench.py --gpus 4 --steps 3 --warm
 import json;d=json.load(open('$O/bench_rehearsal_4ranks_one_gpu.json'));print('rehearsal 4 ranks',d['n_gpus'],d['config']['sample_split'],d['config']['rays_shot_per_step'])"
 timeout -k 10 300 python bench.py --abi-devices 0,0 --steps 3 --warmup 1 --no-cpu-baseline --no-walk-stats > $O/bench_abi_devices_0_0.json 2> $O/abi00.err; python -c "
 import json;d=json.load(open('$O/bench_abi_devices_0_0.json'));print('abi devices 0,0',round(d['value'],1),d['config']['sample_split'],d['config']['rays_shot_per_step'])"
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
