@@ -510,6 +510,10 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 			}
 			s->pair_tree = s->pair_tree && h.materials[h.sky.material].type == RT_MAT_EMIT;
 			s->pair_tree = s->pair_tree && D.lambert_tame != 0u; // (rt_shade.h cosine_is_tame_: these kernels do not read the flag)
+			// ... and the hit record's (p - c) / r goes through the radius' reciprocal without asking (rt_intersect.h
+			// make_sphere_hit_by_reciprocal): both must have passed the host's enumeration (rt_build.cpp, DevPrim::b[1])
+			for (const DevPrim &q : h.dev_prims)
+				s->pair_tree = s->pair_tree && q.b[1] != 0.0f;
 			if (s->pair_tree) { // ... and that scene as kernel arguments, copied from the very records the other kernels read
 				DevPairScene &q = s->pair;
 				std::memcpy(q.c0min, n0.c0min, sizeof q.c0min); std::memcpy(q.c0max, n0.c0max, sizeof q.c0max);
@@ -527,6 +531,8 @@ static int upload_scene(rt_scene *s, const HostScene &h)
 					q.sphere[k][0] = pr.a[0]; q.sphere[k][1] = pr.a[1]; q.sphere[k][2] = pr.a[2]; q.sphere[k][3] = pr.b[0];
 					q.lambert[k][0] = m.tex_c1[0]; q.lambert[k][1] = m.tex_c1[1]; q.lambert[k][2] = m.tex_c1[2]; q.lambert[k][3] = m.param;
 				}
+				q.inv_radius[0] = h.dev_prims[q.slot0].b[1];
+				q.inv_radius[1] = h.dev_prims[q.slot1].b[1];
 				const DevMaterial &sky = h.materials[h.sky.material];
 				q.sky_param = sky.param;
 				q.sky_tex_type = sky.tex_type;

@@ -581,7 +581,7 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 		uint32_t type = kPrimSphere;
 		if (p.type == RT_PRIM_SPHERE) {
 			o.a[0] = p.u.sphere.centre[0]; o.a[1] = p.u.sphere.centre[1]; o.a[2] = p.u.sphere.centre[2];
-			o.b[0] = p.u.sphere.radius;
+			o.b[0] = p.u.sphere.radius; // (b[1]: the radius' verified reciprocal, filled below)
 		} else {
 			type = p.type == RT_PRIM_TRIANGLE ? kPrimTriangle : kPrimMeshTriangle;
 			V3 q[3], nn[3];
@@ -604,6 +604,36 @@ int build_host_scene(const rt_scene_desc *d, HostScene &hs, std::string &err)
 	}
 	});
 
+	{
+		// Spheres: RN(1 / radius) next to the radius, for the hit record's (p - c) / r (rt_intersect.h make_sphere_hit_by_reciprocal)
+		// -- only where the host has verified the reciprocal over every significand (15 ms per distinct radius, cached), and only for
+		// the first few distinct radii of a scene: 0 = not verified, the kernels divide
+		constexpr size_t kMaxVerifiedRadii = 16;
+		std::vector<std::pair<uint32_t, float>> known; // (radius bits, reciprocal or 0)
+		for (uint64_t slot = 0; slot < n; ++slot) {
+			DevPrim &o = hs.dev_prims[slot];
+			uint32_t meta;
+			std::memcpy(&meta, &o.a[3], 4);
+			if ((meta & 3u) != kPrimSphere)
+				continue;
+			uint32_t bits;
+			std::memcpy(&bits, &o.b[0], 4);
+			float rc = 0.0f;
+			bool found = false;
+			for (const auto &k : known)
+				if (k.first == bits) {
+					rc = k.second;
+					found = true;
+					break;
+				}
+			if (!found && known.size() < kMaxVerifiedRadii) {
+				if (!verified_reciprocal(o.b[0], &rc))
+					rc = 0.0f;
+				known.push_back({bits, rc});
+			}
+			o.b[1] = rc;
+		}
+	}
 	lap("device primitive records");
 	// ---- BFS-leaf rank: the order get_intersection_candidates lists leaves in (mod.rs:199-224) ----
 	hs.prim_rank.assign(n, 0);

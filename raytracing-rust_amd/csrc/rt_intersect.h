@@ -262,10 +262,21 @@ __device__ __forceinline__ bool check_side(V3 &normal, V3 ray_direction)
 // for the primitive that won the traversal.  `t` is the value the traversal computed for it; a
 // sphere needs nothing else, a triangle re-runs its intersector for the barycentrics (same code and
 // inputs, so the same t).
-__device__ __forceinline__ void make_sphere_hit(V3 centre, float radius, const Ray &r, float t, Hit &h) // sphere.rs:79-101
+// The sphere's record, with the radius' reciprocal at hand (verified by the host: DevPrim::b[1], DevPairScene::inv_radius; 0 = not
+// verified): the normal's three divisions become three plain operations each (rt_lean.h div_by_verified) when every component of
+// p - c lies in [2^-60, 2^60] by magnitude -- the sequence's domain minus the zeros, whose sign it does not keep; otherwise the
+// plain divisions.  NaN components pass the test or not as min / max ignore them: either way they come out NaN, which is all the
+// filter of the sample asks.  Config 2, same box: 59.74 -> 57.9 ms (profiles/r04ai_sphere_normal_ab.log).
+__device__ __forceinline__ void make_sphere_hit_by_reciprocal(V3 centre, float radius, float inv_radius, const Ray &r, float t, Hit &h) // sphere.rs:79-101
 {
 	const V3 point = r.o + r.d * t;
-	V3 normal = (point - centre) / radius;
+	const V3 x = point - centre;
+	const float lo = fminf(fminf(fabsf(x.x), fabsf(x.y)), fabsf(x.z)), hi = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fabsf(x.z));
+	V3 normal;
+	if (inv_radius != 0.0f && lo >= 0x1p-60f && hi <= 0x1p60f) // (0: this radius was not verified -- never so under FeatPair's contract)
+		normal = v3(div_by_verified(x.x, radius, inv_radius), div_by_verified(x.y, radius, inv_radius), div_by_verified(x.z, radius, inv_radius));
+	else
+		normal = x / radius;
 	bool out = true;
 	if (dot(normal, r.d) > 0.0f) {
 		out = false;
@@ -291,13 +302,13 @@ template <class F> __device__ __forceinline__ void make_hit(const DevScene &S, u
 		const V3 centre = first ? v3(ps.sphere[0][0], ps.sphere[0][1], ps.sphere[0][2]) : v3(ps.sphere[1][0], ps.sphere[1][1], ps.sphere[1][2]);
 		const float radius = first ? ps.sphere[0][3] : ps.sphere[1][3];
 		material = slot;
-		make_sphere_hit(centre, radius, r, t_known, h);
+		make_sphere_hit_by_reciprocal(centre, radius, first ? ps.inv_radius[0] : ps.inv_radius[1], r, t_known, h);
 		return;
 	}
 	const PrimGeom g = load_prim<F>(S, slot);
 	material = g.material;
 	if (!F::tri || g.type == kPrimSphere) {
-		make_sphere_hit(g.p0, g.p1.x, r, t_known, h);
+		make_sphere_hit_by_reciprocal(g.p0, g.p1.x, g.p1.y, r, t_known, h); // (DevPrim::b[1]: the radius' verified reciprocal, or 0)
 		return;
 	}
 	float t = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;

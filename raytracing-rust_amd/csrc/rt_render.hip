@@ -291,6 +291,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::max_block), (KernelSha
 				PS.sphere[0][i] = k->pair.sphere[0][i]; PS.sphere[1][i] = k->pair.sphere[1][i];
 				PS.lambert[0][i] = k->pair.lambert[0][i]; PS.lambert[1][i] = k->pair.lambert[1][i];
 			}
+			PS.inv_radius[0] = k->pair.inv_radius[0]; PS.inv_radius[1] = k->pair.inv_radius[1];
 			PS.sky_param = k->pair.sky_param;
 			PS.sky_tex_type = k->pair.sky_tex_type;
 		}
@@ -820,7 +821,7 @@ __global__ __launch_bounds__((KernelShape<F, FINE, XCHG>::max_block), (KernelSha
 				if (S.single_light != kNoPrim) { // (wave-uniform) as in do_light; a sphere's hit record needs nothing but this record
 					g = load_prim_uniform<F>(&S_global.prims[L.skip]);
 					if (!F::tri || g.type == kPrimSphere) {
-						make_sphere_hit(g.p0, g.p1.x, sr, L.t_limit, lh);
+						make_sphere_hit_by_reciprocal(g.p0, g.p1.x, g.p1.y, sr, L.t_limit, lh);
 						lm = g.material;
 					} else {
 						make_hit<F>(S, L.skip, sr, L.t_limit, lh, lm);

@@ -220,7 +220,8 @@ struct alignas(64) DevPairScene {
 	float sky_param;                              // the sky's Emit: strength,
 	int32_t sky_tex_type;                         // its texture (SolidColour or Lerp)
 	float sky_c1[3], sky_c2[3];
-	uint32_t pad[8];
+	float inv_radius[2];                          // RN(1 / radius): host-verified (rt_build.h verified_reciprocal) -- part of the contract
+	uint32_t pad[6];
 };
 static_assert(sizeof(DevPairScene) == 192, "DevPairScene: three 64-byte lines");
 // (what the kernels of every other feature set pass where a pair scene is expected: never read)
