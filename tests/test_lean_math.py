@@ -63,7 +63,9 @@ def test_division_by_launch_constants_is_verified(hb):
         ok, rc = check(float(c))
         assert ok and rc == np.float32(1.0) / c
     rng = np.random.default_rng(3)
-    for c in (1919.0, 1079.0, 399.0, 224.0, 4095.0, 100.0, 1.0, 2.0, 63.0, 35.0, float(pi)):
+    # (... and the sphere radii of the reference's scenes: the hit record's (p - c) / r goes through the radius' reciprocal,
+    # rt_intersect.h make_sphere_hit_by_reciprocal; rtweekend1's two-sphere kernels require both to pass)
+    for c in (1919.0, 1079.0, 399.0, 224.0, 4095.0, 100.0, 1.0, 2.0, 63.0, 35.0, float(pi), 0.5, 1000.0, 0.45, 0.4):
         ok, rc = check(c)
         assert ok, c  # (every divisor tried so far passes; a failing one would only cost speed: the kernels keep the plain division)
         c32 = np.float32(c)
