@@ -8,6 +8,8 @@ import scenes
 for name in (sys.argv[1:] or ["rtweekend1", "overshadowed"]):
     ls = scenes.load_ssml(name)
     g = hb.HipScene(ls.scene); cam = hb.camera_new(**ls.camera_params)
+    if "SCENE_LDS" in os.environ:  # 0: tiny scenes are read from global memory instead of being staged into LDS
+        g.set_tuning(pkg.abi.RT_TUNE_SCENE_IN_LDS, int(os.environ["SCENE_LDS"]))
     if "FEATURE_SET" in os.environ:  # e.g. 0: the general spheres-only kernel on rtweekend1 instead of the two-sphere special case
         g.set_tuning(pkg.abi.RT_TUNE_FEATURE_SET, int(os.environ["FEATURE_SET"]))
     o = pkg.abi.default_render_opts(1920, 1080, int(os.environ.get("SPP", "1024")), method=1, seed=1)
