@@ -86,7 +86,10 @@ constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase
 #endif
 constexpr uint32_t kDrainLanesHeavy = RT_DRAIN_LANES_HEAVY; // ... the same for the long phases (GEN, SHADE, LIGHT, SCATTER)
 #ifndef RT_NODE_STEPS_PER_VOTE
-#define RT_NODE_STEPS_PER_VOTE 16 // wide tree, 1 M triangles MIS: 8 steps 51.7 ms, 16 steps 52.8, 4 steps 52.7, 32 steps 57.4 (within noise)
+#define RT_NODE_STEPS_PER_VOTE 12 // wide tree, 1 M triangles MIS at 1080p x 256 (ms), round 4, same box, interleaved: 8 steps 964, 10: 942, 11: 929,
+                                  // 12: 928, 13: 932, 14: 936, 16: 949, 24: 1 020, 32: 1 108; 10 M triangles 984 at 12 - 13 against 990 at 16
+                                  // (profiles/r04ar_fine_knobs_ab.log, r04as, r04at_node_steps_ab.log).  Drain thresholds 4 / 5 / 8 / 10 lanes
+                                  // instead of 6: +2.5 / +0.7 / 0.0 / +2.7 %
 #endif
 constexpr int kNodeStepsPerVote = RT_NODE_STEPS_PER_VOTE;
 #ifndef RT_FULL_WAVES
