@@ -82,7 +82,9 @@ constexpr uint32_t kAcquireBatch = RT_ACQUIRE_BATCH; // coarse schedule, tile cl
 #endif
 constexpr uint32_t kDrainLanes = RT_DRAIN_LANES; // fine schedule: a short phase runs once this many lanes wait for it
 #ifndef RT_DRAIN_LANES_HEAVY
-#define RT_DRAIN_LANES_HEAVY RT_DRAIN_LANES
+// (the long phases wait for 8: 1 M triangles, ms, at 12 node steps per vote: 3 lanes 987, 4: 959, 6: 928, 8: 924, 10: 940; 10 M triangles
+// 1 011 / 998 / 987 / 984 / 998 -- profiles/r04au_heavy_drain_ab.log)
+#define RT_DRAIN_LANES_HEAVY 8
 #endif
 constexpr uint32_t kDrainLanesHeavy = RT_DRAIN_LANES_HEAVY; // ... the same for the long phases (GEN, SHADE, LIGHT, SCATTER)
 #ifndef RT_NODE_STEPS_PER_VOTE
